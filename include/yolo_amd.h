@@ -1,0 +1,137 @@
+/*
+ * libyolo_amd.so -- C ABI of the MI355X (gfx950) YOLOv3 inference hot path.
+ *
+ * The reference (jayden199012/yolo) is pure Python with no FFI of its own; the
+ * Python functions named beside each entry point are the interfaces it
+ * replaces.  The drop-in Python modules (yolo_amd/utilis.py, yolo_amd/yolo_v3.py)
+ * bind these symbols with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
+ *     work is enqueued asynchronously on it and nothing synchronises;
+ *   - the caller allocates every buffer, including worst-case outputs and the
+ *     workspace; the library allocates nothing and keeps no global state
+ *     apart from the thread-local last-error string;
+ *   - return value: 0 on success, negative on error (see yolo_amd_last_error).
+ */
+#ifndef YOLO_AMD_H
+#define YOLO_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YOLO_AMD_ABI_VERSION 1
+#define YOLO_AMD_MAX_HEADS 4
+#define YOLO_AMD_MAX_ANCHORS 8
+
+#define YOLO_AMD_LAYOUT_NCHW 0 /* (B, A*D, G, G): what yolo_v3.predict receives */
+#define YOLO_AMD_LAYOUT_NHWC 1 /* (B, G, G, A*D): what the fused conv stack emits */
+
+/* Message describing the last failing call on this thread (host string). */
+const char* yolo_amd_last_error(void);
+int yolo_amd_abi_version(void);
+
+/* ---------------------------------------------------------------- box_iou
+ * Replaces utilis.box_iou(box1, box2)      /root/reference/utilis.py:298-323
+ * box1: n1 x 4 (n1 == 1 broadcasts, else n1 == m), box2: m x 4, corner form,
+ * fp32.  out: m IoUs with the +1 pixel convention, bit-identical to the
+ * reference's fp32 result (same operation order, IEEE division). */
+int yolo_amd_box_iou(const float* box1, int n1, const float* box2, int m, float* out,
+                     void* stream);
+
+/* ---------------------------------------------------------------- decode
+ * Replaces yolo_v3.predict(x, layer, batch_size) for every head at once
+ *                                           /root/reference/yolo_v3.py:205-262
+ * and the two torch.cat calls that assemble the heads (yolo_v3.py:488-493). */
+typedef struct {
+    const float* raw;   /* raw head tensor, fp32, layout below                */
+    int G;              /* grid side                                          */
+    int layout;         /* YOLO_AMD_LAYOUT_NCHW or YOLO_AMD_LAYOUT_NHWC       */
+    int row_offset;     /* first row of this head inside the N_total rows     */
+    float stride;       /* height // G                                        */
+    float anchor_w[YOLO_AMD_MAX_ANCHORS]; /* float32(anchor_w / stride), the  */
+    float anchor_h[YOLO_AMD_MAX_ANCHORS]; /* division done in float64 (host)  */
+} yolo_amd_head_desc;
+
+/* heads: host array.  out: (B, N_total, D) fp32; row (gy*G+gx)*A + a of each
+ * head lands at row_offset + that row. */
+int yolo_amd_decode(const yolo_amd_head_desc* heads, int n_heads, int B, int A, int D,
+                    int N_total, float* out, void* stream);
+
+/* ---------------------------------------------------------------- NMS
+ * Replaces utilis.filter_results(prediction, params) and the
+ * filter_img_class calls inside it      /root/reference/utilis.py:355-465
+ *
+ * pred: (B, N, D) fp32 decoded predictions, D >= 5 + C (never written).
+ * out_rows: room for B*N rows of 9 fp32
+ *           [image, x1, y1, x2, y2, objectness, class score, class index, y1]
+ *           ordered image asc, class asc, objectness desc, original row asc.
+ * out_count: one device int32 that receives K, the number of rows written
+ *            (K == 0 is the reference's "return 0" case).
+ * workspace: 256-byte aligned, at least
+ *            yolo_amd_filter_results_workspace_bytes(B, N, C) bytes. */
+size_t yolo_amd_filter_results_workspace_bytes(int B, int N, int C);
+int yolo_amd_filter_results(const float* pred, int B, int N, int D, int C, float conf,
+                            float nms_thresh, void* workspace, size_t workspace_bytes,
+                            float* out_rows, int* out_count, void* stream);
+
+/* Replaces utilis.filter_img_class(cls, image_pred, ind, nms_thesh)
+ *                                         /root/reference/utilis.py:355-390
+ * rows8: (m, 8) fp32 [x1, y1, x2, y2, objectness, class score, class index,
+ * ymin], 16-byte aligned.  Rows whose class index equals `cls` are sorted by
+ * objectness (descending, ties by row) and greedily suppressed; survivors are
+ * written to out_rows8 (room for m rows) and their number to *out_count. */
+size_t yolo_amd_filter_img_class_workspace_bytes(int m);
+int yolo_amd_filter_img_class(const float* rows8, int m, float cls, float nms_thresh,
+                              void* workspace, size_t workspace_bytes, float* out_rows8,
+                              int* out_count, void* stream);
+
+/* ---------------------------------------------------------------- conv stack
+ * Replaces the conv / upsample / route / shortcut arms of yolo_v3.forward
+ *                                          /root/reference/yolo_v3.py:449-473
+ * executed over nn.Sequential(Conv2d, BatchNorm2d, LeakyReLU) modules built by
+ * utilis.create_module                     /root/reference/utilis.py:169-236
+ *
+ * One descriptor = one fused layer: implicit-GEMM convolution (bf16 inputs,
+ * fp32 accumulation on MFMA) + bias (BatchNorm folded on the host) +
+ * optional LeakyReLU(0.1) + optional residual add (the following shortcut
+ * block) on an input that may be the channel concatenation of a nearest-2x
+ * upsampled tensor and a second tensor (the route block in front of it).
+ * Activations are NHWC bf16; weights are [cout_pad][K_pad] bf16 with
+ * k = (kh*ksize + kw)*Cin + c, zero padded. */
+typedef struct {
+    const void* src0;     /* NHWC bf16, (B, H >> up0, W >> up0, c0); for the   */
+                          /* first layer: NCHW fp32 (B, c0, H, W)               */
+    const void* src1;     /* NHWC bf16 (B, H, W, c1) or NULL                    */
+    const void* weight;   /* packed bf16 (first layer: fp32 [k][cout])          */
+    const float* bias;    /* [cout_pad] fp32                                    */
+    const void* residual; /* NHWC bf16 (B, Ho, Wo, cout) or NULL                */
+    void* dst;            /* NHWC (B, Ho, Wo, cout), bf16 or fp32               */
+    int c0, c1, up0;      /* channels of src0/src1, log2 of src0's upsampling   */
+    int B, H, W;          /* input spatial size seen by the convolution         */
+    int cout, cout_pad;   /* real and padded output channels                    */
+    int ksize, stride;    /* 1 or 3; 1 or 2 (padding = ksize / 2)               */
+    int k_pad;            /* padded reduction length = weight row stride        */
+    int leaky;            /* apply LeakyReLU(0.1)                               */
+    int dst_fp32;         /* 1: dst is fp32 (detection convs), 0: bf16          */
+    int first_layer;      /* 1: src0 is the NCHW fp32 network input             */
+} yolo_amd_conv_desc;
+
+/* Output channels are padded to a whole channel tile: returns the padded
+ * count a weight/bias packer must allocate for `cout` real channels. */
+int yolo_amd_conv_cout_pad(int cout);
+
+/* Run `n` fused layers back to back on `stream`.  descs: host array.
+ * zero_page: >= 256 bytes of device memory holding zeros (padding source). */
+int yolo_amd_conv_forward(const yolo_amd_conv_desc* descs, int n, const void* zero_page,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_AMD_H */

@@ -1,0 +1,111 @@
+"""Helpers for the GPU tests: build the drop-in model with synthetic weights,
+run single fused conv layers through the C ABI."""
+from __future__ import annotations
+
+import ctypes
+import os
+import tempfile
+
+import numpy as np
+import torch
+
+import gen_inputs as gi
+import yolo_oracle as orc
+from yolo_amd.cfg import default_params, write_yolov3_cfg, yolov3_cfg_text
+
+
+def require_gpu():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device (run with -m 'not gpu' on CPU)"
+
+
+def synthetic_snapshot(C, A, seed):
+    """Write the seeded synthetic state_dict to a .pth and return (path, sd)."""
+    blocks = orc.parse_cfg_text(yolov3_cfg_text(C, A))
+    table = orc.layer_table(blocks, 3, C, A)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in gi.synthetic_state_dict(table, seed).items()}
+    fd, path = tempfile.mkstemp(prefix="yolo_amd_", suffix=".pth")
+    os.close(fd)
+    torch.save(sd, path)
+    return path, sd
+
+
+def build_model(H, C=80, A=3, seed=3, confidence=0.5, nms=0.4):
+    """The drop-in yolo_v3 on the GPU, eval mode, synthetic weights loaded
+    through params['pretrain_snapshot'] like a real checkpoint."""
+    from yolo_amd.utilis import parse_cfg
+    from yolo_amd.yolo_v3 import yolo_v3
+    require_gpu()
+    cfg = write_yolov3_cfg(None, C, A)
+    snap, sd = synthetic_snapshot(C, A, seed)
+    params = default_params(H, C, A, cuda=True, confidence=confidence, nms_thesh=nms)
+    params["pretrain_snapshot"] = snap
+    blocks = parse_cfg(cfg)
+    model = yolo_v3(params, blocks)
+    model.eval()
+    os.remove(cfg)
+    os.remove(snap)
+    return model, params, sd
+
+
+def oracle_forward(sd, H, C, A, x_np, return_layers=False):
+    blocks = orc.parse_cfg_text(yolov3_cfg_text(C, A))
+    p = default_params(H, C, A)
+    return orc.forward(sd, blocks, p, torch.from_numpy(x_np), return_layers=return_layers)
+
+
+def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None, fp32_out=False):
+    """One fused layer through yolo_amd_conv_forward.
+
+    x0: (B, H0, W0, c0) bf16 NHWC cuda; x1: optional (B, H, W, c1) bf16;
+    w: (cout, cin, k, k) fp32 (already BN-folded); bias: (cout,) fp32.
+    Returns the NHWC output tensor (bf16, or fp32 when fp32_out)."""
+    from yolo_amd import _lib
+    from yolo_amd._lib import ConvDesc, lib, check
+    dev = x0.device
+    cout, cin, k, _ = w.shape
+    B = x0.shape[0]
+    H, W = x0.shape[1] << up0, x0.shape[2] << up0
+    c0 = x0.shape[3]
+    c1 = 0 if x1 is None else x1.shape[3]
+    assert c0 + c1 == cin
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    cout_pad = lib.yolo_amd_conv_cout_pad(cout)
+    K = k * k * cin
+    wp = torch.zeros((cout_pad, K), dtype=torch.bfloat16, device=dev)
+    wp[:cout] = w.permute(0, 2, 3, 1).reshape(cout, K).to(dev).to(torch.bfloat16)
+    bp = torch.zeros(cout_pad, dtype=torch.float32, device=dev)
+    bp[:cout] = bias.to(dev)
+    out = torch.full((B, Ho, Wo, cout), float("nan"), dtype=torch.float32 if fp32_out else torch.bfloat16,
+                     device=dev)
+    zero = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    d = (ConvDesc * 1)()
+    d[0].src0 = x0.data_ptr()
+    d[0].src1 = None if x1 is None else x1.data_ptr()
+    d[0].weight, d[0].bias = wp.data_ptr(), bp.data_ptr()
+    d[0].residual = None if residual is None else residual.data_ptr()
+    d[0].dst = out.data_ptr()
+    d[0].c0, d[0].c1, d[0].up0 = c0, c1, up0
+    d[0].B, d[0].H, d[0].W = B, H, W
+    d[0].cout, d[0].cout_pad, d[0].ksize, d[0].stride = cout, cout_pad, k, stride
+    d[0].k_pad, d[0].leaky, d[0].dst_fp32, d[0].first_layer = K, int(leaky), int(fp32_out), 0
+    check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), _lib.current_stream_ptr(dev)), "conv")
+    torch.cuda.synchronize()
+    return out
+
+
+def conv_reference(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None):
+    """fp32 torch-CPU reference on the SAME bf16-rounded operands (NHWC in/out)."""
+    import torch.nn.functional as F
+    a = x0.float().cpu().permute(0, 3, 1, 2)
+    if up0:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    if x1 is not None:
+        a = torch.cat((a, x1.float().cpu().permute(0, 3, 1, 2)), 1)
+    wq = w.to(torch.bfloat16).float().cpu()
+    y = F.conv2d(a, wq, bias.float().cpu(), stride=stride, padding=w.shape[2] // 2)
+    if leaky:
+        y = F.leaky_relu(y, 0.1)
+    if residual is not None:
+        y = y + residual.float().cpu().permute(0, 3, 1, 2)
+    return y.permute(0, 2, 3, 1).contiguous()

@@ -1,0 +1,69 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol
+include/yolo_amd.h declares, and its structs have the layout the ctypes
+mirror assumes.  No compute calls here."""
+import ctypes
+import os
+import re
+import subprocess
+import tempfile
+
+from helpers import ROOT
+
+HEADER = os.path.join(ROOT, "include", "yolo_amd.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(yolo_amd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from yolo_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 9
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in names:
+        assert hasattr(raw, name), f"{name} is declared in yolo_amd.h but not exported"
+        assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype in yolo_amd/_lib.py"
+    assert sorted(_lib.SYMBOLS) == names
+    assert _lib.lib.yolo_amd_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    from yolo_amd import _lib
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "yolo_amd.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(yolo_amd_head_desc), offsetof(yolo_amd_head_desc, stride),
+         offsetof(yolo_amd_head_desc, anchor_h), sizeof(yolo_amd_conv_desc),
+         offsetof(yolo_amd_conv_desc, c0), offsetof(yolo_amd_conv_desc, first_layer));
+  return 0;
+}'''
+    with tempfile.TemporaryDirectory() as tmp:
+        c = os.path.join(tmp, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(tmp, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    H, C = _lib.HeadDesc, _lib.ConvDesc
+    want = [ctypes.sizeof(H), H.stride.offset, H.anchor_h.offset, ctypes.sizeof(C), C.c0.offset,
+            C.first_layer.offset]
+    assert got == want
+
+
+def test_host_side_argument_checks_need_no_gpu():
+    from yolo_amd._lib import lib
+    assert lib.yolo_amd_filter_results_workspace_bytes(0, 10, 80) == 0
+    nbytes = lib.yolo_amd_filter_results_workspace_bytes(32, 10647, 80)
+    assert 32 * 10647 * 32 <= nbytes < 32 * 10647 * 40
+    assert lib.yolo_amd_filter_results_workspace_bytes(1, 22743, 80) > 22743 * 32   # keys padded to 32768
+    assert lib.yolo_amd_conv_cout_pad(255) == 256 and lib.yolo_amd_conv_cout_pad(32) == 32
+    assert lib.yolo_amd_conv_cout_pad(64) == 64 and lib.yolo_amd_conv_cout_pad(9) == 32
+    # a null pointer is rejected before anything touches the device
+    rc = lib.yolo_amd_filter_results(None, 1, 10, 85, 80, 0.5, 0.4, None, 0, None, None, None)
+    assert rc < 0 and b"null" in lib.yolo_amd_last_error()
+    rc = lib.yolo_amd_box_iou(None, 3, None, 5, None, None)
+    assert rc < 0 and b"box1" in lib.yolo_amd_last_error()

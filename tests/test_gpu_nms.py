@@ -1,0 +1,147 @@
+"""HIP filter_results / filter_img_class / box_iou against the golden vectors
+(captured from the reference) and the C oracle.  Bit-exact: integer/index work
+and fp32 IoU arithmetic in the reference's order leave no tolerance."""
+import numpy as np
+import pytest
+import torch
+
+import gen_inputs as gi
+import yolo_oracle as orc
+from helpers import (assert_bit_equal, c_filter_results, load_golden, nms_case_input, sha)
+
+pytestmark = pytest.mark.gpu
+
+META, ARR = load_golden()
+NMS_CASES = {c["name"]: c for c in META["nms_cases"]}
+
+
+def hip_filter(pred_np, conf, nms, C, device="cuda"):
+    from yolo_amd.utilis import filter_results
+    t = torch.from_numpy(pred_np).to(device)
+    before = t.clone()
+    out = filter_results(t, {"confidence": conf, "nms_thesh": nms, "num_classes": C})
+    assert torch.equal(t.view(torch.int32), before.view(torch.int32)), "prediction was modified"
+    return out
+
+
+def test_library_is_the_hip_one():
+    from yolo_amd import _lib
+    assert torch.cuda.is_available()
+    assert _lib.lib.yolo_amd_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", [n for n in NMS_CASES if not n.startswith("full")])
+def test_filter_results_golden(name):
+    case = NMS_CASES[name]
+    out = hip_filter(nms_case_input(case), case["conf"], case["nms"], case["gen"]["C"])
+    if case["K"] == 0:
+        assert isinstance(out, int) and out == 0
+        return
+    assert out.is_cuda and out.dtype == torch.float32
+    assert_bit_equal(out.cpu().numpy(), ARR["nms_" + name], name)
+
+
+@pytest.mark.parametrize("name", [n for n in NMS_CASES if n.startswith("full")])
+def test_filter_results_full_size(name):
+    case = NMS_CASES[name]
+    pred = nms_case_input(case)
+    out = hip_filter(pred, case["conf"], case["nms"], case["gen"]["C"]).cpu().numpy()
+    assert out.shape[0] == case["K"]
+    assert sha(out) == case["sha256"]
+    assert_bit_equal(out, c_filter_results(pred, case["conf"], case["nms"], case["gen"]["C"]), name)
+
+
+def test_more_candidates_than_the_lds_sort_holds():
+    # 22743 rows, nearly all pass: the sort runs in global memory
+    pred = gi.nms_pred(seed=61, B=2, N=22743, C=80, H=608)
+    out = hip_filter(pred, 0.01, 0.4, 80).cpu().numpy()
+    assert_bit_equal(out, c_filter_results(pred, 0.01, 0.4, 80), "global sort path")
+
+
+def test_nms_stress_batch():
+    # mAP-eval setting: conf 0.01, 10647 boxes x 80 classes per image
+    pred = gi.nms_pred(seed=62, B=8, N=10647, C=80)
+    out = hip_filter(pred, 0.01, 0.4, 80).cpu().numpy()
+    want = c_filter_results(pred, 0.01, 0.4, 80)
+    assert_bit_equal(out, want, "stress batch")
+    # size-independent properties: ordering and idempotence of the keep set
+    img, cls, obj = out[:, 0], out[:, 7], out[:, 5]
+    key = img * 1000 + cls
+    assert (np.diff(key) >= 0).all()
+    same = np.diff(key) == 0
+    assert (np.diff(obj)[same] <= 0).all()
+
+
+def test_single_class_large_segment():
+    # one class, thousands of boxes in one segment, ties included
+    pred = gi.nms_pred(seed=63, B=2, N=5000, C=1, mode="clustered", tie_levels=256)
+    out = hip_filter(pred, 0.05, 0.4, 1).cpu().numpy()
+    assert_bit_equal(out, c_filter_results(pred, 0.05, 0.4, 1), "single class")
+    pred = gi.nms_pred(seed=64, B=1, N=3000, C=1)
+    out = hip_filter(pred, 0.3, 0.4, 1).cpu().numpy()      # few overlaps: long kept lists
+    assert_bit_equal(out, c_filter_results(pred, 0.3, 0.4, 1), "single class sparse")
+
+
+def test_unaligned_view_and_per_image_calls():
+    # evaluate.py feeds filter_results one image at a time as img.unsqueeze(0):
+    # views that start at 4-byte, not 16-byte, aligned addresses
+    from yolo_amd.utilis import filter_results
+    pred = gi.nms_pred(seed=65, B=3, N=1001, C=7)
+    t = torch.from_numpy(pred).cuda()
+    params = {"confidence": 0.3, "nms_thesh": 0.4, "num_classes": 7}
+    whole = c_filter_results(pred, 0.3, 0.4, 7)
+    for b in range(3):
+        view = t[b].unsqueeze(0)
+        got = filter_results(view, params).cpu().numpy()
+        want = whole[whole[:, 0] == b].copy()
+        want[:, 0] = 0
+        assert_bit_equal(got, want, f"image {b}")
+
+
+def test_confidence_sweep_like_get_map():
+    from yolo_amd.utilis import filter_results
+    pred = gi.nms_pred(seed=66, B=1, N=2000, C=4, mode="clustered")
+    t = torch.from_numpy(pred).cuda()
+    params = {"nms_thesh": 0.4, "num_classes": 4}
+    for conf in list(np.arange(start=0.2, stop=0.95, step=0.025))[::4]:
+        params["confidence"] = conf
+        got = filter_results(t, params)
+        want = c_filter_results(pred, float(np.float32(conf)), 0.4, 4)
+        if want.shape[0] == 0:
+            assert isinstance(got, int) and got == 0
+        else:
+            assert_bit_equal(got.cpu().numpy(), want, f"conf {conf}")
+
+
+def test_cpu_tensor_round_trip():
+    case = NMS_CASES["clustered_n600_c4_conf30"]
+    out = hip_filter(nms_case_input(case), case["conf"], case["nms"], 4, device="cpu")
+    assert not out.is_cuda
+    assert_bit_equal(out.numpy(), ARR["nms_" + case["name"]], "cpu round trip")
+
+
+def test_box_iou_golden():
+    from yolo_amd.utilis import box_iou
+    a, b = gi.iou_pairs(11)
+    ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    assert_bit_equal(box_iou(ta, tb).cpu().numpy(), ARR["iou_pairs"], "pairs")
+    assert_bit_equal(box_iou(ta[100:101], tb).cpu().numpy(), ARR["iou_bcast"], "broadcast")
+    assert box_iou(ta[:1], tb[:0]).shape == (0,)
+
+
+def test_filter_img_class_matches_oracle():
+    from yolo_amd.utilis import filter_img_class
+    pred = gi.nms_pred(seed=67, B=1, N=1500, C=5, mode="clustered", tie_levels=128)
+    rows, n_index = orc.candidates(pred[0], 0.2, 5)
+    t = torch.from_numpy(rows).cuda()
+    for cls in np.unique(rows[:, 6]):
+        sel = np.nonzero(rows[:, 6] == cls)[0]
+        grp = rows[sel]
+        order = np.lexsort((sel, -grp[:, 4].astype(np.float64)))
+        grp = grp[order]
+        want = grp[orc.greedy_nms_sorted(grp, 0.4)]
+        ind, got = filter_img_class(float(cls), t, 3, 0.4)
+        assert_bit_equal(got.cpu().numpy(), want, f"class {cls}")
+        assert ind.shape == (want.shape[0], 1) and (ind == 3).all()
+    ind, got = filter_img_class(99.0, t, 0, 0.4)
+    assert got.shape == (0, 8) and ind.shape == (0, 1)

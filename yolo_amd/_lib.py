@@ -1,0 +1,121 @@
+"""ctypes binding of libyolo_amd.so (the C ABI declared in include/yolo_amd.h).
+
+The library is the product: there is no Python or CPU fallback.  If the shared
+object is missing or a symbol cannot be resolved, importing this module fails
+with instructions to build it (``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C yolo_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo_amd.so")
+
+MAX_HEADS = 4
+MAX_ANCHORS = 8
+LAYOUT_NCHW = 0
+LAYOUT_NHWC = 1
+
+
+class HeadDesc(ctypes.Structure):
+    _fields_ = [
+        ("raw", ctypes.c_void_p),
+        ("G", ctypes.c_int),
+        ("layout", ctypes.c_int),
+        ("row_offset", ctypes.c_int),
+        ("stride", ctypes.c_float),
+        ("anchor_w", ctypes.c_float * MAX_ANCHORS),
+        ("anchor_h", ctypes.c_float * MAX_ANCHORS),
+    ]
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("src0", ctypes.c_void_p),
+        ("src1", ctypes.c_void_p),
+        ("weight", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p),
+        ("dst", ctypes.c_void_p),
+        ("c0", ctypes.c_int), ("c1", ctypes.c_int), ("up0", ctypes.c_int),
+        ("B", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int),
+        ("cout", ctypes.c_int), ("cout_pad", ctypes.c_int),
+        ("ksize", ctypes.c_int), ("stride", ctypes.c_int),
+        ("k_pad", ctypes.c_int),
+        ("leaky", ctypes.c_int),
+        ("dst_fp32", ctypes.c_int),
+        ("first_layer", ctypes.c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/yolo_amd.h declares
+SYMBOLS = {
+    "yolo_amd_last_error": (ctypes.c_char_p, []),
+    "yolo_amd_abi_version": (ctypes.c_int, []),
+    "yolo_amd_box_iou": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "yolo_amd_decode": (ctypes.c_int, [ctypes.POINTER(HeadDesc), ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "yolo_amd_filter_results_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int,
+                                                                  ctypes.c_int]),
+    "yolo_amd_filter_results": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "yolo_amd_filter_img_class_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "yolo_amd_filter_img_class": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                                  ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "yolo_amd_conv_cout_pad": (ctypes.c_int, [ctypes.c_int]),
+    "yolo_amd_conv_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_void_p]),
+}
+
+
+class YoloAmdError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library is the only implementation of this path. "
+            "Build it with `make -C yolo_amd/csrc` (hipcc, --offload-arch=gfx950).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
+        fn.restype = res
+        fn.argtypes = args
+    want = 1
+    got = lib.yolo_amd_abi_version()
+    if got != want:
+        raise ImportError(f"{LIB_PATH} has ABI version {got}, the Python side expects {want}")
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib.yolo_amd_last_error()
+        raise YoloAmdError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def current_stream_ptr(device=None):
+    """hipStream_t of torch's current stream on ``device`` (as an int)."""
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise YoloAmdError("no ROCm device is visible: this path runs on the MI355X HIP kernels "
+                           "only and has no CPU fallback")

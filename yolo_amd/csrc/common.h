@@ -1,0 +1,62 @@
+// Shared helpers for the gfx950 kernels of libyolo_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace yolo_amd {
+
+// ---- error reporting -------------------------------------------------------
+// Every entry point returns 0 on success or a negative code and leaves a
+// message for yolo_amd_last_error().
+enum : int {
+    YA_OK = 0,
+    YA_ERR_ARG = -1,       // bad argument (shape, alignment, null pointer)
+    YA_ERR_HIP = -2,       // a HIP runtime call failed
+    YA_ERR_WORKSPACE = -3, // workspace too small
+    YA_ERR_UNSUPPORTED = -4,
+};
+
+void set_error(const char* fmt, ...);
+
+#define YA_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            yolo_amd::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+                                __FILE__, __LINE__);                                    \
+            return yolo_amd::YA_ERR_HIP;                                                \
+        }                                                                               \
+    } while (0)
+
+#define YA_REQUIRE(cond, ...)                      \
+    do {                                           \
+        if (!(cond)) {                             \
+            yolo_amd::set_error(__VA_ARGS__);      \
+            return yolo_amd::YA_ERR_ARG;           \
+        }                                          \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline uint32_t next_pow2(uint32_t x) {
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+}  // namespace yolo_amd
+
+#include "common_host.h"
+
+namespace yolo_amd {
+
+__device__ __forceinline__ uint32_t fdiv_u32(uint32_t n, FastDiv f) {
+    if (f.d == 1) return n;
+    // Granlund-Montgomery round-up form: q = (hi + ((n - hi) >> 1)) >> (l - 1)
+    uint32_t hi = __umulhi(n, f.mul);
+    return (hi + ((n - hi) >> 1)) >> (f.shift - 1);
+}
+
+}  // namespace yolo_amd

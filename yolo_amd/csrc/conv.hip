@@ -1,0 +1,412 @@
+// Fused convolution layers of the Darknet-53 / YOLOv3 graph for gfx950.
+//
+// One launch = conv (1x1 or 3x3, stride 1 or 2, padding ksize/2) + bias
+// (BatchNorm folded on the host) + LeakyReLU(0.1) + residual add, reading an
+// input that may be concat(upsample2x(src0), src1).  This is what
+// yolo_v3.forward executes block by block through nn.Sequential(Conv2d,
+// BatchNorm2d, LeakyReLU), nn.Upsample, torch.cat and the in-place shortcut
+// add (/root/reference/yolo_v3.py:449-473, /root/reference/utilis.py:169-236).
+//
+// Formulation: implicit GEMM  D[channel][pixel] = sum_k W[channel][k] * X[k][pixel]
+// with k = (kh*ksize + kw)*Cin + c, activations NHWC bf16, fp32 accumulation
+// on v_mfma_f32_16x16x32_bf16.  Weights are the MFMA "A" operand and pixels
+// the "B" operand, so every lane ends up owning 4 consecutive output channels
+// of one pixel: the epilogue packs them into one 8-byte NHWC store.
+//
+// Both operand tiles are staged into LDS by LDS-DMA (global_load_lds_dwordx4):
+// each lane supplies the global address of one 16-byte chunk, which is how the
+// im2col gather, the zero padding (lanes outside the image read a zero page),
+// the nearest-neighbour upsample and the concat are all folded into addressing
+// with no extra pass over memory.  Two LDS stages: the loads of K-tile t+1 are
+// in flight while the MFMAs of tile t run; one barrier per K-tile.
+#include "common.h"
+#include "conv_layout.h"
+#include "../../include/yolo_amd.h"
+
+namespace yolo_amd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const __bf16* src0;
+    const __bf16* src1;
+    const __bf16* wgt;
+    const float* bias;
+    const __bf16* res;
+    void* dst;
+    const __bf16* zero;
+    int C0, C1, up0;
+    int H, W, Ho, Wo, M;
+    int Cout, Kpad, ksize, stride;
+    int leaky, dst_fp32;
+    int tiles_m, tiles_n;
+    FastDiv divHoWo, divWo;
+};
+
+__device__ __forceinline__ void lds_dma16(const __bf16* gsrc, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int BM, int BN, int BK, int WAVES_M>
+__global__ void __launch_bounds__(256)
+conv_igemm_kernel(const ConvArgs a) {
+    constexpr int CH = BK / 8;                 // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CH;               // tile rows filled by one wave-instruction
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WMP = BM / WAVES_M;          // pixels per wave
+    constexpr int WNC = BN / WAVES_N;          // channels per wave
+    constexpr int TP = WMP / 16, TC = WNC / 16;
+    constexpr int TA = BM * CH / 64;           // wave-instructions per activation tile
+    constexpr int TB = BN * CH / 64;           // ... per weight tile
+    constexpr int NA = (TA + 3) / 4, NB = (TB + 3) / 4;   // per wave
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int KSTEPS = BK / 32;
+    static_assert(WMP % 16 == 0 && WNC % 16 == 0, "wave tile must be a multiple of 16x16");
+
+    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w % WAVES_M, wn = w / WAVES_M;
+
+    // XCD-aware tile order: blocks that share blockIdx % 8 share an L2; give
+    // each such group a contiguous run of tiles, channel tiles fastest, so the
+    // blocks that re-read one pixel tile run on one XCD close in time.
+    int tile;
+    {
+        const int T = a.tiles_m * a.tiles_n;
+        const int q = T >> 3, r = T & 7;
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int Cin = a.C0 + a.C1;
+    const int H0 = a.H >> a.up0, W0 = a.W >> a.up0;
+
+    // ---- per-lane source bookkeeping for the LDS-DMA slots this lane fills
+    int off0[NA], off1[NA], vmask[NA], woff[NB];
+    int koff;                                   // element offset of this lane's chunk in a K-tile
+    {
+        const int cprime = lane % CH;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int j = i * 4 + w;
+            const int row = j * RPI + lane / CH;
+            if (i == 0) koff = (cprime ^ chunk_swizzle<BK>(row)) * 8;   // same for every i (see conv_layout.h)
+            const int m = m0 + row;
+            const bool vm = (j < TA) && (m < a.M);
+            const int mm = vm ? m : 0;
+            const uint32_t b = fdiv_u32((uint32_t)mm, a.divHoWo);
+            const uint32_t rem = (uint32_t)mm - b * (uint32_t)(a.Ho * a.Wo);
+            const uint32_t oy = fdiv_u32(rem, a.divWo);
+            const uint32_t ox = rem - oy * (uint32_t)a.Wo;
+            const int iyc = (int)oy * a.stride, ixc = (int)ox * a.stride;
+            off0[i] = (((int)b * H0 + (iyc >> a.up0)) * W0 + (ixc >> a.up0)) * a.C0;
+            off1[i] = (((int)b * a.H + iyc) * a.W + ixc) * a.C1;
+            int vbits = 0;
+            if (vm) {
+                if (a.ksize == 1) {
+                    vbits = 1;
+                } else {
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int iy = iyc + kh - 1, ix = ixc + kw - 1;
+                            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) vbits |= 1 << (kh * 3 + kw);
+                        }
+                }
+            }
+            vmask[i] = vbits;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = i * 4 + w;
+            const int row = j * RPI + lane / CH;
+            woff[i] = (n0 + row) * a.Kpad + koff;
+        }
+    }
+
+    // ---- uniform K-tile walker: (tap, channel) of the current tile
+    int k_c = 0, k_tap = 0, k_kh = 0, k_kw = 0;
+    const int pad = a.ksize >> 1;
+
+    auto stage = [&](int buf, int kt) {
+        char* sA = lds + buf * STAGE;
+        char* sB = sA + A_BYTES;
+        const bool second = k_c >= a.C0;
+        const __bf16* base = second ? a.src1 : a.src0;
+        const int Csrc = second ? a.C1 : a.C0;
+        const int Wsrc = second ? a.W : W0;
+        const int delta = ((k_kh - pad) * Wsrc + (k_kw - pad)) * Csrc + (second ? k_c - a.C0 : k_c) + koff;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int j = i * 4 + w;
+            if ((TA % 4 == 0) || j < TA) {
+                const bool v = (vmask[i] >> k_tap) & 1;
+                const int eo = (second ? off1[i] : off0[i]) + delta;
+                const __bf16* p = v ? (base + eo) : a.zero;
+                lds_dma16(p, sA + j * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = i * 4 + w;
+            if ((TB % 4 == 0) || j < TB) lds_dma16(a.wgt + (woff[i] + kt * BK), sB + j * 1024);
+        }
+        // advance the walker
+        k_c += BK;
+        if (k_c >= Cin) {
+            k_c = 0;
+            ++k_tap;
+            if (++k_kw == a.ksize) { k_kw = 0; ++k_kh; }
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a tile), one per k-step
+    int frag_off[KSTEPS];
+    {
+        const int r15 = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) frag_off[ks] = slot_of<BK>(r15, ks * 4 + q) * 16;
+    }
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = a.Kpad / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+        const char* sA = lds + cur * STAGE + (wm * WMP) * (BK * 2);
+        const char* sB = lds + cur * STAGE + A_BYTES + (wn * WNC) * (BK * 2);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            bf16x8 wf[TC], xf[TP];
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc)
+                wf[tc] = *reinterpret_cast<const bf16x8*>(sB + tc * 16 * (BK * 2) + frag_off[ks]);
+#pragma unroll
+            for (int tp = 0; tp < TP; ++tp)
+                xf[tp] = *reinterpret_cast<const bf16x8*>(sA + tp * 16 * (BK * 2) + frag_off[ks]);
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc)
+#pragma unroll
+                for (int tp = 0; tp < TP; ++tp)
+                    acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: bias, LeakyReLU, residual, store
+    const int px = lane & 15, cq = (lane >> 4) * 4;
+    const bool vec = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int tp = 0; tp < TP; ++tp) {
+        const int m = m0 + wm * WMP + tp * 16 + px;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+            const int ch = n0 + wn * WNC + tc * 16 + cq;
+            if (ch >= a.Cout) continue;
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + ch);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[tc][tp][r] + bs[r];
+                if (a.leaky) x = x > 0.f ? x : 0.1f * x;
+                v[r] = x;
+            }
+            const size_t o = (size_t)m * a.Cout + ch;
+            if (vec) {
+                if (a.res) {
+                    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(a.res + o);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rr[r];
+                }
+                if (a.dst_fp32) {
+                    *reinterpret_cast<f32x4*>((float*)a.dst + o) = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[r] = (__bf16)v[r];
+                    *reinterpret_cast<bf16x4*>((__bf16*)a.dst + o) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (ch + r >= a.Cout) break;
+                    float x = v[r];
+                    if (a.res) x += (float)a.res[o + r];
+                    if (a.dst_fp32) ((float*)a.dst)[o + r] = x;
+                    else ((__bf16*)a.dst)[o + r] = (__bf16)x;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- first layer
+// Network input is NCHW fp32 with very few channels (3): K = 9*Cin is far too
+// short for an MFMA pipeline and the layer is bound by its 64-byte-per-pixel
+// output stream, so it is a direct convolution: one thread per output pixel,
+// weights (fp32 [k][cout], k = (kh*3 + kw)*Cin + c) broadcast from LDS.
+template <int COUT>
+__global__ void __launch_bounds__(256)
+conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
+                  const float* __restrict__ bias, __bf16* __restrict__ dst, int Cin, int H, int W,
+                  int M, int leaky, FastDiv divHW, FastDiv divW) {
+    __shared__ __attribute__((aligned(16))) float sw[36 * COUT];
+    const int K = 9 * Cin;
+    for (int i = threadIdx.x; i < K * COUT; i += 256) sw[i] = wgt[i];
+    __syncthreads();
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t b = fdiv_u32((uint32_t)m, divHW);
+    const uint32_t rem = (uint32_t)m - b * (uint32_t)(H * W);
+    const int oy = (int)fdiv_u32(rem, divW);
+    const int ox = (int)rem - oy * W;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
+    const float* img = src + (size_t)b * Cin * H * W;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int iy = oy + kh - 1;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ix = ox + kw - 1;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            for (int c = 0; c < Cin; ++c) {
+                const float x = ok ? img[((size_t)c * H + iy) * W + ix] : 0.f;
+                const float* wk = sw + ((kh * 3 + kw) * Cin + c) * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; co += 4) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wk + co);
+                    acc[co + 0] += x * w4[0];
+                    acc[co + 1] += x * w4[1];
+                    acc[co + 2] += x * w4[2];
+                    acc[co + 3] += x * w4[3];
+                }
+            }
+        }
+    }
+    __bf16* o = dst + (size_t)m * COUT;
+#pragma unroll
+    for (int co = 0; co < COUT; co += 8) {
+        bf16x8 pk;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float x = acc[co + r];
+            if (leaky) x = x > 0.f ? x : 0.1f * x;
+            pk[r] = (__bf16)x;
+        }
+        *reinterpret_cast<bf16x8*>(o + co) = pk;
+    }
+}
+
+// ---------------------------------------------------------------- launch
+static int pick_bk(int c0, int c1) { return (c0 % 64 == 0 && c1 % 64 == 0) ? 64 : 32; }
+static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
+
+template <int BM, int BN, int BK, int WAVES_M>
+static void launch_igemm(const ConvArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M>), dim3(a.tiles_m * a.tiles_n), dim3(256),
+                       0, stream, a);
+}
+
+static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream) {
+    YA_REQUIRE(d.src0 && d.weight && d.bias && d.dst, "conv: null pointer");
+    YA_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.cout > 0, "conv: bad shape");
+    YA_REQUIRE((d.ksize == 1 || d.ksize == 3) && (d.stride == 1 || d.stride == 2),
+               "conv: ksize=%d stride=%d unsupported", d.ksize, d.stride);
+    const int pad = d.ksize / 2;
+    const int Ho = (d.H + 2 * pad - d.ksize) / d.stride + 1;
+    const int Wo = (d.W + 2 * pad - d.ksize) / d.stride + 1;
+    const long long M = (long long)d.B * Ho * Wo;
+    YA_REQUIRE(M < (1ll << 31), "conv: too many output pixels");
+    if (d.first_layer) {
+        YA_REQUIRE(d.ksize == 3 && d.stride == 1 && d.c0 >= 1 && d.c0 <= 4 && d.c1 == 0 && !d.residual &&
+                       !d.dst_fp32 && d.up0 == 0,
+                   "conv: first layer must be 3x3 stride 1 with at most 4 input channels");
+        FastDiv dHW = make_fastdiv((uint32_t)(d.H * d.W)), dW = make_fastdiv((uint32_t)d.W);
+        dim3 grid((unsigned)((M + 255) / 256));
+        if (d.cout == 32) {
+            hipLaunchKernelGGL(conv_first_kernel<32>, grid, dim3(256), 0, stream, (const float*)d.src0,
+                               (const float*)d.weight, d.bias, (__bf16*)d.dst, d.c0, d.H, d.W, (int)M,
+                               d.leaky, dHW, dW);
+        } else if (d.cout == 16) {
+            hipLaunchKernelGGL(conv_first_kernel<16>, grid, dim3(256), 0, stream, (const float*)d.src0,
+                               (const float*)d.weight, d.bias, (__bf16*)d.dst, d.c0, d.H, d.W, (int)M,
+                               d.leaky, dHW, dW);
+        } else {
+            set_error("conv: first layer with %d output channels is not instantiated (16 or 32)", d.cout);
+            return YA_ERR_UNSUPPORTED;
+        }
+        return YA_OK;
+    }
+    YA_REQUIRE(zero_page, "conv: zero page missing");
+    YA_REQUIRE(d.c0 % 32 == 0 && d.c1 % 32 == 0 && d.c0 > 0 && d.c1 >= 0,
+               "conv: input channels (%d, %d) must be multiples of 32", d.c0, d.c1);
+    YA_REQUIRE(d.c1 == 0 || d.src1, "conv: src1 missing");
+    YA_REQUIRE(d.up0 == 0 || (d.up0 == 1 && d.ksize == 1 && d.H % 2 == 0 && d.W % 2 == 0),
+               "conv: an upsampled source is supported for 1x1 convolutions only");
+    const int BK = pick_bk(d.c0, d.c1), BN = pick_bn(d.cout);
+    const int K = d.ksize * d.ksize * (d.c0 + d.c1);
+    YA_REQUIRE(d.k_pad == K && K % BK == 0, "conv: k_pad=%d, expected %d", d.k_pad, K);
+    YA_REQUIRE(d.cout_pad % BN == 0 && d.cout_pad >= d.cout, "conv: cout_pad=%d not a multiple of %d", d.cout_pad, BN);
+    YA_REQUIRE((long long)d.B * d.H * d.W * (d.c0 + d.c1) < (1ll << 31) && (long long)d.cout_pad * K < (1ll << 31),
+               "conv: tensor too large for 32-bit element offsets");
+    ConvArgs a;
+    a.src0 = (const __bf16*)d.src0; a.src1 = (const __bf16*)d.src1; a.wgt = (const __bf16*)d.weight;
+    a.bias = d.bias; a.res = (const __bf16*)d.residual; a.dst = d.dst; a.zero = (const __bf16*)zero_page;
+    a.C0 = d.c0; a.C1 = d.c1; a.up0 = d.up0; a.H = d.H; a.W = d.W; a.Ho = Ho; a.Wo = Wo; a.M = (int)M;
+    a.Cout = d.cout; a.Kpad = K; a.ksize = d.ksize; a.stride = d.stride; a.leaky = d.leaky;
+    a.dst_fp32 = d.dst_fp32;
+    constexpr int BM = 128;
+    a.tiles_m = (int)((M + BM - 1) / BM);
+    a.tiles_n = d.cout_pad / BN;
+    a.divHoWo = make_fastdiv((uint32_t)(Ho * Wo));
+    a.divWo = make_fastdiv((uint32_t)Wo);
+    if (BN == 128 && BK == 64) launch_igemm<128, 128, 64, 2>(a, stream);
+    else if (BN == 128 && BK == 32) launch_igemm<128, 128, 32, 2>(a, stream);
+    else if (BN == 64 && BK == 64) launch_igemm<128, 64, 64, 2>(a, stream);
+    else if (BN == 64 && BK == 32) launch_igemm<128, 64, 32, 2>(a, stream);
+    else if (BN == 32 && BK == 64) launch_igemm<128, 32, 64, 4>(a, stream);
+    else launch_igemm<128, 32, 32, 4>(a, stream);
+    return YA_OK;
+}
+
+}  // namespace yolo_amd
+
+using namespace yolo_amd;
+
+extern "C" int yolo_amd_conv_cout_pad(int cout) {
+    if (cout <= 0) return 0;
+    const int bn = pick_bn(cout);
+    return (cout + bn - 1) / bn * bn;
+}
+
+extern "C" int yolo_amd_conv_forward(const yolo_amd_conv_desc* descs, int n, const void* zero_page,
+                                     void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    YA_REQUIRE(descs && n >= 0, "conv_forward: null descriptor array");
+    for (int i = 0; i < n; ++i) {
+        int rc = launch_conv(descs[i], zero_page, stream);
+        if (rc != YA_OK) return rc;
+    }
+    YA_CHECK_HIP(hipGetLastError());
+    return YA_OK;
+}

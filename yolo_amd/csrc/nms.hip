@@ -1,0 +1,494 @@
+// Confidence filter + per-class greedy NMS (filter_results) and box_iou for
+// gfx950.  Restates /root/reference/utilis.py:298-323 (box_iou), :355-390
+// (filter_img_class) and :393-465 (filter_results) as five small kernels:
+//
+//   compact  : stream the (B,N,D) tensor once through LDS; for every row with
+//              objectness > conf compute corners, first-index class argmax and
+//              a 64-bit sort key; wave-ballot compaction into per-image lists
+//   sort     : one workgroup per image, LDS bitonic sort of the keys
+//              (class asc, objectness desc, original row asc) and segment
+//              boundaries per (image, class)
+//   suppress : one wave per (image, class) segment, greedy suppression in
+//              64-box chunks (IoU in the reference's fp32 operation order)
+//   scan     : exclusive scan of kept counts -> output row offsets, total K
+//   gather   : write the (K, 9) rows
+//
+// All arithmetic that decides a keep/suppress outcome is plain IEEE fp32 with
+// no contraction (the file is built with -ffp-contract=off) and correctly
+// rounded division, so kept rows are bit-identical to the reference's.
+#include "common.h"
+#include "../../include/yolo_amd.h"
+
+namespace yolo_amd {
+
+// torch.max / torch.min / torch.clamp propagate NaN; fmaxf/fminf do not.
+__device__ __forceinline__ float tmax(float a, float b) {
+    return (a != a) ? a : ((b != b) ? b : (a > b ? a : b));
+}
+__device__ __forceinline__ float tmin(float a, float b) {
+    return (a != a) ? a : ((b != b) ? b : (a < b ? a : b));
+}
+
+// utilis.py:298-323, same operation order, +1 pixel convention.
+__device__ __forceinline__ float iou_ref(float4 p, float4 q) {
+    float ix1 = tmax(p.x, q.x);
+    float iy1 = tmax(p.y, q.y);
+    float ix2 = tmin(p.z, q.z);
+    float iy2 = tmin(p.w, q.w);
+    float iw = tmax(__fadd_rn(__fsub_rn(ix2, ix1), 1.0f), 0.0f);
+    float ih = tmax(__fadd_rn(__fsub_rn(iy2, iy1), 1.0f), 0.0f);
+    float inter = __fmul_rn(iw, ih);
+    float a1 = __fmul_rn(__fadd_rn(__fsub_rn(p.z, p.x), 1.0f), __fadd_rn(__fsub_rn(p.w, p.y), 1.0f));
+    float a2 = __fmul_rn(__fadd_rn(__fsub_rn(q.z, q.x), 1.0f), __fadd_rn(__fsub_rn(q.w, q.y), 1.0f));
+    float uni = __fsub_rn(__fadd_rn(a1, a2), inter);
+    return __fdiv_rn(inter, uni);
+}
+
+// ---------------------------------------------------------------- box_iou
+__global__ void __launch_bounds__(256)
+box_iou_kernel(const float* __restrict__ b1, int n1, const float* __restrict__ b2, int m,
+               float* __restrict__ out) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const float* p = b1 + (n1 == 1 ? 0 : 4 * (size_t)i);
+    const float* q = b2 + 4 * (size_t)i;
+    out[i] = iou_ref(make_float4(p[0], p[1], p[2], p[3]), make_float4(q[0], q[1], q[2], q[3]));
+}
+
+// ---------------------------------------------------------------- keys
+// key = class << 52 | ~ordered(objectness) << 20 | row, where ordered() is the
+// usual order-preserving map from fp32 to uint32 (flip the sign bit of
+// non-negative values, all bits of negative ones); inverting it sorts
+// descending.  row < 2^20, class < 2^12.
+constexpr int KEY_ROW_BITS = 20;
+constexpr int KEY_CLS_SHIFT = 52;
+__device__ __forceinline__ unsigned long long make_key(int cls, float obj, int row) {
+    unsigned int u = __float_as_uint(obj);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    unsigned int ob = ~u;
+    return ((unsigned long long)cls << KEY_CLS_SHIFT) | ((unsigned long long)ob << KEY_ROW_BITS) |
+           (unsigned long long)row;
+}
+__device__ __forceinline__ int key_cls(unsigned long long k) { return (int)(k >> KEY_CLS_SHIFT); }
+__device__ __forceinline__ int key_row(unsigned long long k) { return (int)(k & ((1u << KEY_ROW_BITS) - 1)); }
+__device__ __forceinline__ float key_obj(unsigned long long k) {
+    unsigned int u = ~(unsigned int)(k >> KEY_ROW_BITS);
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(u);
+}
+
+// ---------------------------------------------------------------- compact
+// Block = WAVES waves; each wave owns a tile of 64 consecutive rows of one
+// image and stages its 64*D floats through its own LDS slice with fully
+// coalesced loads (16 B per lane when the tile base allows it, else 4 B).
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+nms_compact_kernel(const float* __restrict__ pred, int N, int D, int C, float conf,
+                   int key_stride, int* __restrict__ cand_count,
+                   unsigned long long* __restrict__ keys, float4* __restrict__ boxes,
+                   float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int row0 = (blockIdx.x * WAVES + wave) * 64;
+    float* tile = lds + (size_t)wave * 64 * D;
+    const int rows = min(64, N - row0);            // may be <= 0 for the tail wave
+    if (rows > 0) {
+        const float* src = pred + ((size_t)b * N + row0) * D;
+        const int nfl = rows * D;
+        if (((uintptr_t)src & 15) == 0) {
+            const int n4 = nfl >> 2;
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* t4 = reinterpret_cast<float4*>(tile);
+            for (int i = lane; i < n4; i += 64) t4[i] = s4[i];
+            for (int i = (n4 << 2) + lane; i < nfl; i += 64) tile[i] = src[i];
+        } else {
+            for (int i = lane; i < nfl; i += 64) tile[i] = src[i];
+        }
+    }
+    __syncthreads();
+    bool pass = false;
+    float obj = 0.f;
+    const float* r = tile + lane * D;
+    if (lane < rows) {
+        obj = r[4];
+        pass = (obj > conf) && (obj > 0.0f);
+    }
+    unsigned long long m = __ballot(pass);
+    if (m == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&cand_count[b], __popcll(m));
+    base = __shfl(base, 0);
+    if (pass) {
+        // first-index maximum; a NaN beats every number and the first NaN wins
+        float best = r[5];
+        int bi = 0;
+        for (int j = 1; j < C; ++j) {
+            float v = r[5 + j];
+            if ((v > best) || ((v != v) && !(best != best))) { best = v; bi = j; }
+        }
+        float cx = r[0], cy = r[1], w = r[2], h = r[3];
+        float hw = __fdiv_rn(w, 2.0f), hh = __fdiv_rn(h, 2.0f);
+        float4 bx = make_float4(__fsub_rn(cx, hw), __fsub_rn(cy, hh), __fadd_rn(cx, hw), __fadd_rn(cy, hh));
+        const int row = row0 + lane;
+        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+        keys[(size_t)b * key_stride + slot] = make_key(bi, obj, row);
+        boxes[(size_t)b * N + row] = bx;
+        scores[(size_t)b * N + row] = best;
+    }
+}
+
+// ---------------------------------------------------------------- sort
+constexpr int SORT_THREADS = 1024;
+constexpr int SORT_LDS_KEYS = 16384;     // 128 KiB of the CU's 160 KiB LDS
+
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_sort(Ptr s, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += SORT_THREADS) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int l = i | j;
+                bool up = (i & k) == 0;
+                unsigned long long a = s[i], c = s[l];
+                if ((a > c) == up) { s[i] = c; s[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SORT_THREADS)
+nms_sort_kernel(const int* __restrict__ cand_count, int key_stride, int C,
+                unsigned long long* __restrict__ keys, int* __restrict__ seg_start,
+                int* __restrict__ seg_end) {
+    __shared__ unsigned long long skeys[SORT_LDS_KEYS];
+    const int b = blockIdx.x;
+    const int cnt = cand_count[b];
+    unsigned long long* gk = keys + (size_t)b * key_stride;
+    for (int c = threadIdx.x; c < C; c += SORT_THREADS) {
+        seg_start[b * C + c] = 0;
+        seg_end[b * C + c] = 0;
+    }
+    if (cnt == 0) return;
+    int P = 1;
+    while (P < cnt) P <<= 1;
+    const unsigned long long* sorted;
+    if (P <= SORT_LDS_KEYS) {
+        for (int i = threadIdx.x; i < P; i += SORT_THREADS) skeys[i] = (i < cnt) ? gk[i] : ~0ull;
+        __syncthreads();
+        bitonic_sort(skeys, P);
+        for (int i = threadIdx.x; i < cnt; i += SORT_THREADS) gk[i] = skeys[i];
+        sorted = skeys;
+    } else {
+        // more candidates than the LDS holds: same network in global memory
+        // (key_stride >= P is guaranteed by the host)
+        for (int i = cnt + threadIdx.x; i < P; i += SORT_THREADS) gk[i] = ~0ull;
+        __threadfence_block();
+        __syncthreads();
+        bitonic_sort(gk, P);
+        sorted = gk;
+    }
+    // (seg_start/seg_end zeroing above is ordered before these writes by the
+    // barriers inside bitonic_sort, or by this one when P == 1)
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += SORT_THREADS) {
+        int c = key_cls(sorted[i]);
+        if (i == 0 || key_cls(sorted[i - 1]) != c) seg_start[b * C + c] = i;
+        if (i == cnt - 1 || key_cls(sorted[i + 1]) != c) seg_end[b * C + c] = i + 1;
+    }
+}
+
+// ---------------------------------------------------------------- suppress
+// One wave per (image, class).  Boxes are visited in sorted order in chunks of
+// 64 (one per lane).  A chunk is first tested against every box kept from
+// earlier chunks, then resolved internally pivot by pivot.  A box survives iff
+// `iou < thresh` holds against every earlier kept box, so iou >= thresh and
+// NaN both suppress (utilis.py:379-385).
+constexpr int KEPT_LDS = 1024;           // kept boxes cached in LDS per segment
+
+__global__ void __launch_bounds__(64)
+nms_suppress_kernel(const unsigned long long* __restrict__ keys, int key_stride, int N, int C,
+                    const int* __restrict__ seg_start, const int* __restrict__ seg_end,
+                    const float4* __restrict__ boxes, int box_stride, float thresh,
+                    int* __restrict__ kept_pos, int* __restrict__ seg_kept) {
+    __shared__ float4 kept_box[KEPT_LDS];
+    __shared__ float4 chunk_box[64];
+    const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int s = seg_start[b * C + c], e = seg_end[b * C + c];
+    const int n = e - s;
+    if (n <= 0) {
+        if (lane == 0) seg_kept[b * C + c] = 0;
+        return;
+    }
+    const unsigned long long* gk = keys + (size_t)b * key_stride + s;
+    const float4* gb = boxes + (size_t)b * N * box_stride;
+    int* kp = kept_pos + (size_t)b * N + s;   // kept sorted positions, segment-local order
+    int nk = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int idx = base + lane;
+        bool alive = idx < n;
+        float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (alive) mine = gb[(size_t)key_row(gk[idx]) * box_stride];
+        chunk_box[lane] = mine;
+        // against boxes kept from earlier chunks
+        for (int k = 0; k < nk; ++k) {
+            float4 kb = (k < KEPT_LDS) ? kept_box[k] : gb[(size_t)key_row(gk[kp[k]]) * box_stride];
+            if (alive && !(iou_ref(kb, mine) < thresh)) alive = false;
+            if ((k & 15) == 15 && __ballot(alive) == 0) break;
+        }
+        __syncthreads();
+        // inside the chunk, pivot by pivot
+        unsigned long long m = __ballot(alive);
+        while (m) {
+            const int i = __ffsll((long long)m) - 1;
+            float4 pb = chunk_box[i];
+            if (lane > i && alive && !(iou_ref(pb, mine) < thresh)) alive = false;
+            m = __ballot(alive);
+            m = (i >= 63) ? 0ull : (m & ~((2ull << i) - 1ull));
+        }
+        // append survivors
+        m = __ballot(alive);
+        if (alive) {
+            const int r = nk + __popcll(m & ((1ull << lane) - 1ull));
+            if (r < KEPT_LDS) kept_box[r] = mine;
+            kp[r] = idx;
+        }
+        nk += __popcll(m);
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (lane == 0) seg_kept[b * C + c] = nk;
+}
+
+// ---------------------------------------------------------------- scan
+__global__ void __launch_bounds__(1024)
+nms_scan_kernel(const int* __restrict__ seg_kept, int S, int* __restrict__ seg_off,
+                int* __restrict__ total) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (S + 1023) / 1024;
+    const int lo = min(S, t * per), hi = min(S, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += seg_kept[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        int v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - sum;                 // exclusive prefix of this thread's range
+    for (int i = lo; i < hi; ++i) {
+        seg_off[i] = run;
+        run += seg_kept[i];
+    }
+    if (t == 1023) *total = part[1023];
+}
+
+// ---------------------------------------------------------------- gather
+// Row = [image, x1, y1, x2, y2, objectness, class score, class index, y1]
+// (utilis.py:397-411 makes the 9th value alias ymin).
+__global__ void __launch_bounds__(64)
+nms_gather_kernel(const unsigned long long* __restrict__ keys, int key_stride, int N, int C,
+                  const int* __restrict__ seg_start, const int* __restrict__ seg_kept,
+                  const int* __restrict__ seg_off, const int* __restrict__ kept_pos,
+                  const float4* __restrict__ boxes, const float* __restrict__ scores,
+                  float* __restrict__ out) {
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int nk = seg_kept[b * C + c];
+    if (nk == 0) return;
+    const int s = seg_start[b * C + c];
+    const int off = seg_off[b * C + c];
+    const unsigned long long* gk = keys + (size_t)b * key_stride + s;
+    const int* kp = kept_pos + (size_t)b * N + s;
+    for (int r = threadIdx.x; r < nk; r += 64) {
+        unsigned long long k = gk[kp[r]];
+        int row = key_row(k);
+        float4 bx = boxes[(size_t)b * N + row];
+        float* o = out + (size_t)(off + r) * 9;
+        o[0] = (float)b;
+        o[1] = bx.x; o[2] = bx.y; o[3] = bx.z; o[4] = bx.w;
+        o[5] = key_obj(k);
+        o[6] = scores[(size_t)b * N + row];
+        o[7] = (float)c;
+        o[8] = bx.y;
+    }
+}
+
+
+// ---------------------------------------------------------------- filter_img_class
+// Single-class entry: rows are (m, 8) fp32 [x1,y1,x2,y2,obj,score,cls,ymin]
+// (utilis.py:355-390).  Rows whose class column equals `cls` are selected;
+// rows with objectness == 0 never survive the reference's nonzero() pass.
+__global__ void __launch_bounds__(256)
+rows8_keys_kernel(const float* __restrict__ rows8, int m, float cls, int* __restrict__ count,
+                  unsigned long long* __restrict__ keys) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool pass = false;
+    float obj = 0.f;
+    if (r < m) {
+        obj = rows8[(size_t)r * 8 + 4];
+        pass = (rows8[(size_t)r * 8 + 6] == cls) && (obj != 0.0f);
+    }
+    unsigned long long mk = __ballot(pass);
+    if (mk == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, __popcll(mk));
+    base = __shfl(base, 0);
+    if (pass) keys[base + __popcll(mk & ((1ull << lane) - 1ull))] = make_key(0, obj, r);
+}
+
+__global__ void __launch_bounds__(64)
+rows8_gather_kernel(const unsigned long long* __restrict__ keys, const int* __restrict__ seg_kept,
+                    const int* __restrict__ kept_pos, const float* __restrict__ rows8,
+                    float* __restrict__ out) {
+    const int nk = seg_kept[0];
+    for (int r = blockIdx.x * 64 + threadIdx.x; r < nk; r += gridDim.x * 64) {
+        const int row = key_row(keys[kept_pos[r]]);
+        const float4* src = reinterpret_cast<const float4*>(rows8 + (size_t)row * 8);
+        float4* dst = reinterpret_cast<float4*>(out + (size_t)r * 8);
+        dst[0] = src[0];
+        dst[1] = src[1];
+    }
+}
+
+// ---------------------------------------------------------------- workspace
+struct NmsWorkspace {
+    int* cand_count;     // [B]
+    int* total;          // [1]  (lives in the caller's out_count instead when given)
+    int* seg_start;      // [B*C]
+    int* seg_end;        // [B*C]
+    int* seg_kept;       // [B*C]
+    int* seg_off;        // [B*C]
+    unsigned long long* keys;  // [B][key_stride]
+    float4* boxes;       // [B][N]
+    float* scores;       // [B][N]
+    int* kept_pos;       // [B][N]
+    int key_stride;
+    size_t bytes;
+    size_t zero_bytes;   // leading region that must be zeroed before every call
+};
+
+static NmsWorkspace carve(void* base, int B, int N, int C) {
+    NmsWorkspace w;
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* r = p + off; off = align_up(off + bytes, 256); return r; };
+    w.cand_count = (int*)take(sizeof(int) * (size_t)B);
+    w.zero_bytes = off;
+    w.total = (int*)take(sizeof(int));
+    const size_t S = (size_t)B * C;
+    w.seg_start = (int*)take(sizeof(int) * S);
+    w.seg_end = (int*)take(sizeof(int) * S);
+    w.seg_kept = (int*)take(sizeof(int) * S);
+    w.seg_off = (int*)take(sizeof(int) * S);
+    w.key_stride = (N <= SORT_LDS_KEYS) ? N : (int)next_pow2((uint32_t)N);
+    w.keys = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)B * w.key_stride);
+    w.boxes = (float4*)take(sizeof(float4) * (size_t)B * N);
+    w.scores = (float*)take(sizeof(float) * (size_t)B * N);
+    w.kept_pos = (int*)take(sizeof(int) * (size_t)B * N);
+    w.bytes = off;
+    return w;
+}
+
+}  // namespace yolo_amd
+
+using namespace yolo_amd;
+
+extern "C" size_t yolo_amd_filter_results_workspace_bytes(int B, int N, int C) {
+    if (B <= 0 || N <= 0 || C <= 0) return 0;
+    return carve(nullptr, B, N, C).bytes;
+}
+
+extern "C" int yolo_amd_filter_results(const float* pred, int B, int N, int D, int C, float conf,
+                                       float nms_thresh, void* workspace, size_t workspace_bytes,
+                                       float* out_rows, int* out_count, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    YA_REQUIRE(pred && workspace && out_rows && out_count, "filter_results: null pointer");
+    YA_REQUIRE(B > 0 && N > 0 && C > 0, "filter_results: B, N, C must be positive (got %d, %d, %d)", B, N, C);
+    YA_REQUIRE(D >= 5 + C, "filter_results: D=%d is smaller than 5 + C=%d", D, 5 + C);
+    YA_REQUIRE(N < (1 << KEY_ROW_BITS), "filter_results: N=%d exceeds the %d-bit row field", N, KEY_ROW_BITS);
+    YA_REQUIRE(C < (1 << (64 - KEY_CLS_SHIFT)), "filter_results: C=%d exceeds the class field", C);
+    YA_REQUIRE(((uintptr_t)pred & 3) == 0 && ((uintptr_t)workspace & 255) == 0,
+               "filter_results: pred must be 4-byte and workspace 256-byte aligned");
+    YA_REQUIRE((size_t)B * C < (1u << 30) && B <= 65535, "filter_results: B*C too large");
+    NmsWorkspace w = carve(workspace, B, N, C);
+    if (workspace_bytes < w.bytes) {
+        set_error("filter_results: workspace holds %zu bytes, %zu needed", workspace_bytes, w.bytes);
+        return YA_ERR_WORKSPACE;
+    }
+    YA_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, stream));
+
+    // compact: LDS per wave = 64*D floats; fewer waves per block for wide rows
+    const size_t wave_lds = (size_t)64 * D * sizeof(float);
+    YA_REQUIRE(wave_lds <= 150 * 1024, "filter_results: D=%d rows do not fit the LDS tile", D);
+    if (wave_lds * 2 <= 64 * 1024) {
+        dim3 grid((N + 127) / 128, B);
+        hipLaunchKernelGGL(nms_compact_kernel<2>, grid, dim3(128), wave_lds * 2, stream, pred, N, D, C,
+                           conf, w.key_stride, w.cand_count, w.keys, w.boxes, w.scores);
+    } else {
+        dim3 grid((N + 63) / 64, B);
+        hipLaunchKernelGGL(nms_compact_kernel<1>, grid, dim3(64), wave_lds, stream, pred, N, D, C,
+                           conf, w.key_stride, w.cand_count, w.keys, w.boxes, w.scores);
+    }
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(SORT_THREADS), 0, stream, w.cand_count,
+                       w.key_stride, C, w.keys, w.seg_start, w.seg_end);
+    hipLaunchKernelGGL(nms_suppress_kernel, dim3(C, B), dim3(64), 0, stream, w.keys, w.key_stride, N, C,
+                       w.seg_start, w.seg_end, w.boxes, 1, nms_thresh, w.kept_pos, w.seg_kept);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, B * C, w.seg_off,
+                       out_count);
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(C, B), dim3(64), 0, stream, w.keys, w.key_stride, N, C,
+                       w.seg_start, w.seg_kept, w.seg_off, w.kept_pos, w.boxes, w.scores, out_rows);
+    YA_CHECK_HIP(hipGetLastError());
+    return YA_OK;
+}
+
+
+extern "C" size_t yolo_amd_filter_img_class_workspace_bytes(int m) {
+    if (m <= 0) return 0;
+    return carve(nullptr, 1, m, 1).bytes;
+}
+
+extern "C" int yolo_amd_filter_img_class(const float* rows8, int m, float cls, float nms_thresh,
+                                         void* workspace, size_t workspace_bytes, float* out_rows8,
+                                         int* out_count, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    YA_REQUIRE(rows8 && workspace && out_rows8 && out_count, "filter_img_class: null pointer");
+    YA_REQUIRE(m > 0 && m < (1 << KEY_ROW_BITS), "filter_img_class: m=%d out of range", m);
+    YA_REQUIRE(((uintptr_t)rows8 & 15) == 0 && ((uintptr_t)out_rows8 & 15) == 0 &&
+                   ((uintptr_t)workspace & 255) == 0,
+               "filter_img_class: rows must be 16-byte and workspace 256-byte aligned");
+    NmsWorkspace w = carve(workspace, 1, m, 1);
+    if (workspace_bytes < w.bytes) {
+        set_error("filter_img_class: workspace holds %zu bytes, %zu needed", workspace_bytes, w.bytes);
+        return YA_ERR_WORKSPACE;
+    }
+    YA_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, stream));
+    hipLaunchKernelGGL(rows8_keys_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, rows8, m, cls,
+                       w.cand_count, w.keys);
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(SORT_THREADS), 0, stream, w.cand_count,
+                       w.key_stride, 1, w.keys, w.seg_start, w.seg_end);
+    hipLaunchKernelGGL(nms_suppress_kernel, dim3(1, 1), dim3(64), 0, stream, w.keys, w.key_stride, m, 1,
+                       w.seg_start, w.seg_end, reinterpret_cast<const float4*>(rows8), 2, nms_thresh,
+                       w.kept_pos, w.seg_kept);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, 1, w.seg_off,
+                       out_count);
+    hipLaunchKernelGGL(rows8_gather_kernel, dim3(min(256, (m + 63) / 64)), dim3(64), 0, stream, w.keys,
+                       w.seg_kept, w.kept_pos, rows8, out_rows8);
+    YA_CHECK_HIP(hipGetLastError());
+    return YA_OK;
+}
+
+extern "C" int yolo_amd_box_iou(const float* box1, int n1, const float* box2, int m, float* out,
+                                void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    YA_REQUIRE(m >= 0 && (n1 == 1 || n1 == m), "box_iou: box1 must hold 1 or m=%d boxes (got %d)", m, n1);
+    if (m == 0) return YA_OK;
+    YA_REQUIRE(box1 && box2 && out, "box_iou: null pointer");
+    hipLaunchKernelGGL(box_iou_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, box1, n1, box2, m, out);
+    YA_CHECK_HIP(hipGetLastError());
+    return YA_OK;
+}

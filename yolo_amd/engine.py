@@ -1,0 +1,358 @@
+"""Execution plan for the fused inference path.
+
+Turns the cfg blocks + the model's parameters into what the HIP library runs:
+
+  * BatchNorm folded into bf16 weights [cout_pad][kh][kw][cin] and an fp32 bias
+    (recomputed whenever weights are reloaded);
+  * one ``yolo_amd_conv_desc`` per convolution, with the following shortcut
+    block folded in as a residual operand and the preceding upsample / route
+    blocks folded into the source addressing, so the 107-block graph
+    (/root/reference/yolo_v3.py:449-496) becomes 75 kernel launches;
+  * NHWC bf16 activation buffers placed in one arena by liveness, so the hot
+    working set stays small enough to live in the 256 MiB Infinity Cache for
+    the deeper layers;
+  * three fp32 NHWC detection-conv outputs that the decode kernel turns into
+    the (B, N, 5+C) prediction tensor in one launch.
+
+Nothing here computes on the CPU; host code only builds descriptors.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, HeadDesc, check, lib
+
+
+class UnsupportedGraph(NotImplementedError):
+    pass
+
+
+def graph_from_blocks(blocks, channels, num_classes, num_anchors,
+                      detection_layers=(81, 93, 105)):
+    """Per-block table: type, shapes-independent attributes, absolute sources."""
+    det = (num_classes + 5) * num_anchors
+    table, out_ch = [], []
+    cin = channels
+    n_yolo = 0
+    for i, blk in enumerate(blocks):
+        t = blk["type"]
+        if t == "convolutional":
+            cout = det if i in detection_layers else int(blk["filters"])
+            k = int(blk["size"])
+            ent = dict(type="conv", cin=cin, cout=cout, k=k, stride=int(blk["stride"]),
+                       bn=bool("batch_normalize" in blk and blk["batch_normalize"]),
+                       leaky=blk["activation"] == "leaky")
+            cin = cout
+        elif t == "upsample":
+            ent = dict(type="upsample", stride=int(blk["stride"]))
+        elif t == "route":
+            items = [int(s) for s in blk["layers"].split(",")]
+            srcs = [i + items[0]] + ([items[1]] if len(items) == 2 else [])
+            if len(items) > 2:
+                raise Exception("Route layer is not behaving as we planned, please "
+                                "change the code according.")
+            ent = dict(type="route", srcs=srcs)
+            cin = sum(out_ch[s] for s in srcs)
+        elif t == "shortcut":
+            ent = dict(type="shortcut", src=i + int(blk["from"]))
+        elif t == "yolo":
+            ent = dict(type="yolo", head=n_yolo)
+            n_yolo += 1
+        else:
+            raise UnsupportedGraph(f"block {i}: unknown type {t!r}")
+        ent["cout"] = cin
+        out_ch.append(cin)
+        table.append(ent)
+    return table
+
+
+class _Val:
+    """A tensor flowing between blocks: one or two NHWC parts."""
+    __slots__ = ("parts", "H", "W")
+
+    def __init__(self, parts, H, W):
+        self.parts = parts        # list of (buffer_id, channels, up_log2)
+        self.H, self.W = H, W
+
+
+def build_ops(table, B, H, channels):
+    """Pure host pass over the block table: which convolution reads what.
+
+    Returns (ops, heads, buf_info):
+      ops      one dict per convolution in execution order (sources, shapes,
+               fused residual, fp32 output flag)
+      heads    [(buffer id, G)] for the yolo blocks, in file order
+      buf_info buffer id -> dict(bytes, first, last) with first/last the block
+               indices between which the buffer must stay intact
+    """
+    vals = [None] * len(table)
+    ops, heads, buf_info = [], [], {}
+    cur = _Val([("input", int(channels), 0)], H, H)
+
+    def touch(bid, i):
+        if bid != "input":
+            buf_info[bid]["last"] = max(buf_info[bid]["last"], i)
+
+    i, n = 0, len(table)
+    while i < n:
+        ent = table[i]
+        t = ent["type"]
+        if t == "conv":
+            k, s = ent["k"], ent["stride"]
+            pad = k // 2
+            Ho = (cur.H + 2 * pad - k) // s + 1
+            Wo = (cur.W + 2 * pad - k) // s + 1
+            if len(cur.parts) > 2:
+                raise UnsupportedGraph(f"block {i}: more than two concatenated inputs")
+            if len(cur.parts) == 2 and cur.parts[1][2] != 0:
+                raise UnsupportedGraph(f"block {i}: only the first concat input may be upsampled")
+            if cur.parts[0][2] not in (0, 1) or (cur.parts[0][2] == 1 and k != 1):
+                raise UnsupportedGraph(f"block {i}: upsampled input into a {k}x{k} convolution")
+            to_yolo = i + 1 < n and table[i + 1]["type"] == "yolo"
+            fuse_res = i + 1 < n and table[i + 1]["type"] == "shortcut"
+            op = dict(index=i, ent=ent, src=list(cur.parts), H=cur.H, W=cur.W, Ho=Ho, Wo=Wo,
+                      fp32=to_yolo, res=None, first=(cur.parts[0][0] == "input"))
+            for bid, _, _ in cur.parts:
+                touch(bid, i)
+            elem = 4 if to_yolo else 2
+            bid = f"L{i}"
+            buf_info[bid] = dict(bytes=B * Ho * Wo * ent["cout"] * elem, first=i, last=i)
+            out = _Val([(bid, ent["cout"], 0)], Ho, Wo)
+            vals[i] = out
+            if fuse_res:
+                sc = table[i + 1]
+                rv = vals[sc["src"]]
+                if rv is None or len(rv.parts) != 1 or rv.parts[0][2] != 0 or \
+                        rv.parts[0][1] != ent["cout"] or rv.H != Ho or rv.W != Wo or to_yolo:
+                    raise UnsupportedGraph(f"block {i + 1}: shortcut operand shape mismatch")
+                op["res"] = rv.parts[0][0]
+                touch(op["res"], i)
+                vals[i + 1] = out          # the add happens in place in the conv output
+                i += 1
+            ops.append(op)
+            cur = out
+        elif t == "upsample":
+            if ent["stride"] != 2 or len(cur.parts) != 1 or cur.parts[0][2] != 0:
+                raise UnsupportedGraph(f"block {i}: only a single 2x nearest upsample is fused")
+            bid, c, _ = cur.parts[0]
+            cur = _Val([(bid, c, 1)], cur.H * 2, cur.W * 2)
+            vals[i] = cur
+        elif t == "route":
+            srcs = [vals[s] for s in ent["srcs"]]
+            if any(v is None for v in srcs):
+                raise UnsupportedGraph(f"block {i}: route refers to a block with no tensor")
+            if len(srcs) == 1:
+                cur = srcs[0]
+            else:
+                a, b = srcs
+                if a.H != b.H or a.W != b.W or len(a.parts) != 1 or len(b.parts) != 1:
+                    raise UnsupportedGraph(f"block {i}: concat of mismatched tensors")
+                cur = _Val([a.parts[0], b.parts[0]], a.H, a.W)
+            vals[i] = cur
+        elif t == "shortcut":
+            raise UnsupportedGraph(f"block {i}: shortcut that does not follow a convolution")
+        elif t == "yolo":
+            if len(cur.parts) != 1 or not ops or ops[-1]["index"] != i - 1:
+                raise UnsupportedGraph(f"block {i}: yolo block must follow its detection conv")
+            bid = cur.parts[0][0]
+            buf_info[bid]["last"] = 10 ** 9        # alive until the decode launch
+            heads.append((bid, cur.H))
+            vals[i] = cur
+            if len(heads) == 3:
+                break
+        i += 1
+    if not heads:
+        raise UnsupportedGraph("cfg has no yolo block")
+    return ops, heads, buf_info
+
+
+def place_buffers(buf_info):
+    """First-fit placement by liveness, 256-byte aligned.  Returns
+    ({buffer id: offset}, arena bytes)."""
+    order = sorted(buf_info.items(), key=lambda kv: kv[1]["first"])
+    placed = []            # (offset, end, last)
+    offsets = {}
+    peak = 0
+    for bid, info in order:
+        size = (info["bytes"] + 255) // 256 * 256
+        live = sorted((o, e) for (o, e, last) in placed if last >= info["first"])
+        pos = 0
+        for o, e in live:
+            if pos + size <= o:
+                break
+            pos = max(pos, e)
+        offsets[bid] = pos
+        placed.append((pos, pos + size, info["last"]))
+        peak = max(peak, pos + size)
+    return offsets, peak
+
+
+class Plan:
+    """Descriptors and buffers for one (batch, height) shape on one device."""
+
+    def __init__(self, model, B, H):
+        _lib.require_gpu()
+        self.model = model
+        self.B, self.H = B, H
+        params = model.params
+        self.C = int(params["num_classes"])
+        self.A = int(params["num_anchors"])
+        self.D = 5 + self.C
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise _lib.YoloAmdError("the model's parameters are on the CPU; call model.cuda() "
+                                    "(params['cuda'] = True): the fused path runs on the GPU only")
+        self.table = graph_from_blocks(model.blocks, int(params["channels"]), self.C, self.A)
+        self.stage_events = None      # set to a list to collect per-stage HIP events
+        self._build()
+
+    # ------------------------------------------------------------------ build
+    def _build(self):
+        B, H = self.B, self.H
+        dev = self.device
+        ops, heads, buf_info = build_ops(self.table, B, H, int(self.model.params["channels"]))
+        self.ops, self.heads = ops, heads
+        offsets, peak = place_buffers(buf_info)
+        self.arena = torch.empty(peak + 256, dtype=torch.uint8, device=dev)
+        self.arena_bytes = peak
+        base = (self.arena.data_ptr() + 255) // 256 * 256
+        self.buf_ptr = {bid: base + off for bid, off in offsets.items()}
+        self.zero_page = torch.zeros(1024, dtype=torch.uint8, device=dev)
+
+        # ---- descriptors
+        self.descs = (ConvDesc * len(ops))()
+        for j, op in enumerate(ops):
+            ent, d = op["ent"], self.descs[j]
+            (b0, c0, up0) = op["src"][0]
+            d.src0 = 0 if b0 == "input" else self.buf_ptr[b0]
+            d.c0, d.up0 = c0, up0
+            if len(op["src"]) == 2:
+                d.src1, d.c1 = self.buf_ptr[op["src"][1][0]], op["src"][1][1]
+            else:
+                d.src1, d.c1 = None, 0
+            d.residual = self.buf_ptr[op["res"]] if op["res"] else None
+            d.dst = self.buf_ptr[f"L{op['index']}"]
+            d.B, d.H, d.W = B, op["H"], op["W"]
+            d.cout = ent["cout"]
+            d.cout_pad = ent["cout"] if op["first"] else lib.yolo_amd_conv_cout_pad(ent["cout"])
+            d.ksize, d.stride = ent["k"], ent["stride"]
+            d.k_pad = ent["k"] * ent["k"] * (c0 + d.c1)
+            d.leaky = int(ent["leaky"])
+            d.dst_fp32 = int(op["fp32"])
+            d.first_layer = int(op["first"])
+        self.refold()
+
+        # ---- decode descriptors
+        stride_rows = 0
+        self.head_descs = (HeadDesc * len(heads))()
+        anchors = np.asarray(self.model.params["anchors"], dtype=np.float64)
+        for k, (bid, G) in enumerate(heads):
+            hd = self.head_descs[k]
+            hd.raw = self.buf_ptr[bid]
+            hd.G = G
+            hd.layout = _lib.LAYOUT_NHWC
+            hd.row_offset = stride_rows
+            stride = H // G
+            hd.stride = float(stride)
+            # anchors may have been reassigned on the yolo_layer modules
+            layer_anchors = self._head_anchors(k, anchors)
+            for a in range(self.A):
+                hd.anchor_w[a] = np.float32(layer_anchors[a][0] / stride)
+                hd.anchor_h[a] = np.float32(layer_anchors[a][1] / stride)
+            stride_rows += G * G * self.A
+        self.N = stride_rows
+
+    def _head_anchors(self, k, anchors):
+        idx = [i for i, e in enumerate(self.table) if e["type"] == "yolo"][k]
+        mod = self.model.module_list[idx]
+        layer = mod[0] if len(mod) else None
+        if layer is not None and getattr(layer, "anchors", None) is not None:
+            return np.asarray(layer.anchors, dtype=np.float64)
+        return anchors[k * self.A:(k + 1) * self.A]
+
+    # ------------------------------------------------------------------ weights
+    @torch.no_grad()
+    def refold(self):
+        """(Re)compute folded weights from the model's current parameters."""
+        self._packed = []
+        for j, op in enumerate(self.ops):
+            i, ent, d = op["index"], op["ent"], self.descs[j]
+            seq = self.model.module_list[i]
+            conv = seq[0]
+            w = conv.weight.detach().float()
+            cout = w.shape[0]
+            if ent["bn"]:
+                bn = seq[1]
+                scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
+                bias = bn.bias.detach().float() - bn.running_mean.float() * scale
+                if conv.bias is not None:
+                    bias = bias + conv.bias.detach().float() * scale
+                w = w * scale.view(-1, 1, 1, 1)
+            else:
+                bias = conv.bias.detach().float() if conv.bias is not None else w.new_zeros(cout)
+            wk = w.permute(0, 2, 3, 1).reshape(cout, -1)          # [cout][(kh,kw,cin)]
+            if op["first"]:
+                wp = wk.t().contiguous()                           # fp32 [k][cout]
+                bp = bias.contiguous()
+            else:
+                wp = torch.zeros((d.cout_pad, d.k_pad), dtype=torch.bfloat16, device=w.device)
+                wp[:cout, :wk.shape[1]] = wk.to(torch.bfloat16)
+                bp = torch.zeros(d.cout_pad, dtype=torch.float32, device=w.device)
+                bp[:cout] = bias
+            self._packed.append((wp, bp))
+            d.weight = wp.data_ptr()
+            d.bias = bp.data_ptr()
+
+    # ------------------------------------------------------------------ run
+    def run(self, x):
+        """x: (B, C, H, H) fp32 contiguous on the plan's device.  Returns the
+        (B, N, 5+C) fp32 prediction tensor (asynchronous on the current stream)."""
+        if x.shape[0] != self.B or x.shape[2] != self.H or x.shape[3] != self.H:
+            raise ValueError("input shape does not match the plan")
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        self.descs[0].src0 = x.data_ptr()
+        out = torch.empty((self.B, self.N, self.D), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = _lib.current_stream_ptr(self.device)
+            ev = None
+            if self.stage_events is not None:
+                # HIP events on the launch stream around the conv stack and the
+                # decode launch (read back by bench.py after the timed region)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+            check(lib.yolo_amd_conv_forward(self.descs, len(self.ops), self.zero_page.data_ptr(),
+                                            stream), "conv_forward")
+            if ev:
+                ev[1].record()
+            check(lib.yolo_amd_decode(self.head_descs, len(self.heads), self.B, self.A, self.D,
+                                      self.N, out.data_ptr(), stream), "decode")
+            if ev:
+                ev[2].record()
+                self.stage_events.append(ev)
+        self._keepalive = x
+        return out
+
+    def run_convs_only(self, x):
+        """Conv stack without the decode launch (bench timing of the stages)."""
+        self.descs[0].src0 = x.data_ptr()
+        with torch.cuda.device(self.device):
+            check(lib.yolo_amd_conv_forward(self.descs, len(self.ops), self.zero_page.data_ptr(),
+                                            _lib.current_stream_ptr(self.device)), "conv_forward")
+
+    def layer_output(self, index):
+        """Debug/test view of a conv output buffer as an NHWC tensor."""
+        for op in self.ops:
+            if op["index"] == index:
+                dt = torch.float32 if op["fp32"] else torch.bfloat16
+                n = self.B * op["Ho"] * op["Wo"] * op["ent"]["cout"]
+                esize = 4 if op["fp32"] else 2
+                off = self.buf_ptr[f"L{index}"] - self.arena.data_ptr()
+                flat = self.arena[off:off + n * esize].view(dt)
+                return flat.view(self.B, op["Ho"], op["Wo"], op["ent"]["cout"])
+        raise KeyError(index)
