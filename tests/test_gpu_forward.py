@@ -154,7 +154,11 @@ def test_forward_layers_and_output(case):
     torch.cuda.synchronize()
     assert list(det.shape) == case["out_shape"] and det.dtype == torch.float32 and det.is_cuda
     want, outs = oracle_forward(sd, H, C, A, x_np, return_layers=True)
-    plan = model._plan(B, H)
+    from yolo_amd.engine import Plan
+    plan = Plan(model, B, H, keep_all=True)         # no buffer reuse: every layer stays readable
+    det_keep = plan.run(torch.from_numpy(x_np).cuda())
+    torch.cuda.synchronize()
+    assert torch.equal(det_keep, det), "buffer placement changes the result"
     worst = 0.0
     for op in plan.ops:
         i = op["index"]

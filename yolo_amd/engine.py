@@ -194,8 +194,11 @@ def place_buffers(buf_info):
 class Plan:
     """Descriptors and buffers for one (batch, height) shape on one device."""
 
-    def __init__(self, model, B, H):
+    def __init__(self, model, B, H, keep_all=False):
+        """keep_all=True gives every layer its own buffer (no reuse) so tests can
+        inspect intermediate outputs after a run."""
         _lib.require_gpu()
+        self.keep_all = keep_all
         self.model = model
         self.B, self.H = B, H
         params = model.params
@@ -216,6 +219,9 @@ class Plan:
         dev = self.device
         ops, heads, buf_info = build_ops(self.table, B, H, int(self.model.params["channels"]))
         self.ops, self.heads = ops, heads
+        if self.keep_all:
+            for info in buf_info.values():
+                info["last"] = 10 ** 9
         offsets, peak = place_buffers(buf_info)
         self.arena = torch.empty(peak + 256, dtype=torch.uint8, device=dev)
         self.arena_bytes = peak
