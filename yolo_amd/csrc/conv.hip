@@ -19,6 +19,8 @@
 // the nearest-neighbour upsample and the concat are all folded into addressing
 // with no extra pass over memory.  Two LDS stages: the loads of K-tile t+1 are
 // in flight while the MFMAs of tile t run; one barrier per K-tile.
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_layout.h"
 #include "../../include/yolo_amd.h"
@@ -50,7 +52,23 @@ __device__ __forceinline__ void lds_dma16(const __bf16* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int BM, int BN, int BK, int WAVES_M>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// wait until at most `stages` of the youngest stages (PER loads each) are in flight
+template <int MAXS, int PER>
+__device__ __forceinline__ void wait_stages(int stages) {
+    if constexpr (MAXS == 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (stages >= MAXS) wait_vmcnt<MAXS * PER>();
+        else wait_stages<MAXS - 1, PER>(stages);
+    }
+}
+
+template <int BM, int BN, int BK, int WAVES_M, int NSTAGE>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvArgs a) {
     constexpr int CH = BK / 8;                 // 16-byte chunks per tile row
@@ -65,9 +83,14 @@ conv_igemm_kernel(const ConvArgs a) {
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int KSTEPS = BK / 32;
+    constexpr int PRE = NSTAGE - 1;            // stages issued ahead of the one being computed
+    // counted waits need every wave to issue the same number of loads per stage
+    constexpr bool UNIFORM = (TA % 4 == 0) && (TB % 4 == 0);
+    constexpr int LPS = UNIFORM ? NA + NB : 0; // LDS-DMA instructions per wave per stage
     static_assert(WMP % 16 == 0 && WNC % 16 == 0, "wave tile must be a multiple of 16x16");
+    static_assert(NSTAGE >= 2 && (PRE - 1) * (NA + NB) < 64, "vmcnt holds 6 bits");
 
-    __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+    __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE];
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -183,13 +206,20 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int tp = 0; tp < TP; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Ring of NSTAGE LDS stages.  Stage t+PRE is issued while tile t is being
+    // multiplied, so PRE-1 whole stages stay in flight across each barrier.
+    // The wait is counted (never vmcnt(0) in the steady state) and the barrier
+    // is a bare s_barrier: a __syncthreads() here would drain the DMA queue.
     const int KT = a.Kpad / BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
+#pragma unroll
+    for (int s = 0; s < PRE; ++s)
+        if (s < KT) stage(s, s);
+    int cur = 0, nxt = PRE % NSTAGE;
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) stage(cur ^ 1, kt + 1);
+        wait_stages<PRE - 1, LPS>(min(PRE - 1, KT - 1 - kt));   // this wave's part of tile kt landed
+        __builtin_amdgcn_s_barrier();                          // everyone's did; tile kt-1 fully read
+        asm volatile("" ::: "memory");
+        if (kt + PRE < KT) stage(nxt, kt + PRE);
         const char* sA = lds + cur * STAGE + (wm * WMP) * (BK * 2);
         const char* sB = lds + cur * STAGE + A_BYTES + (wn * WNC) * (BK * 2);
 #pragma unroll
@@ -207,9 +237,8 @@ conv_igemm_kernel(const ConvArgs a) {
                 for (int tp = 0; tp < TP; ++tp)
                     acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+        nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
     }
 
     // ---- epilogue: bias, LeakyReLU, residual, store
@@ -321,10 +350,18 @@ conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
 static int pick_bk(int c0, int c1) { return (c0 % 64 == 0 && c1 % 64 == 0) ? 64 : 32; }
 static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
 
-template <int BM, int BN, int BK, int WAVES_M>
+template <int BM, int BN, int BK, int WAVES_M, int NSTAGE>
 static void launch_igemm(const ConvArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M>), dim3(a.tiles_m * a.tiles_n), dim3(256),
-                       0, stream, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, NSTAGE>), dim3(a.tiles_m * a.tiles_n),
+                       dim3(256), 0, stream, a);
+}
+
+// Development knob: YOLO_AMD_CONV_NSTAGE / YOLO_AMD_CONV_BK override the ring
+// depth / K tile of the 128-channel-tile kernel so variants can be timed
+// against each other in one process (tools/conv_bench.py).
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
 }
 
 static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream) {
@@ -363,7 +400,12 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     YA_REQUIRE(d.c1 == 0 || d.src1, "conv: src1 missing");
     YA_REQUIRE(d.up0 == 0 || (d.up0 == 1 && d.ksize == 1 && d.H % 2 == 0 && d.W % 2 == 0),
                "conv: an upsampled source is supported for 1x1 convolutions only");
-    const int BK = pick_bk(d.c0, d.c1), BN = pick_bn(d.cout);
+    int BK = pick_bk(d.c0, d.c1);
+    const int BN = pick_bn(d.cout);
+    // K tile 32 keeps LDS at 32 KiB per workgroup (more resident workgroups);
+    // 64 only pays for the widest inputs
+    const int want_bk = env_int("YOLO_AMD_CONV_BK", (d.c0 + d.c1 >= 512) ? 64 : 32);
+    if (BK == 64 && want_bk == 32) BK = 32;
     const int K = d.ksize * d.ksize * (d.c0 + d.c1);
     YA_REQUIRE(d.k_pad == K && K % BK == 0, "conv: k_pad=%d, expected %d", d.k_pad, K);
     YA_REQUIRE(d.cout_pad % BN == 0 && d.cout_pad >= d.cout, "conv: cout_pad=%d not a multiple of %d", d.cout_pad, BN);
@@ -380,12 +422,30 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     a.tiles_n = d.cout_pad / BN;
     a.divHoWo = make_fastdiv((uint32_t)(Ho * Wo));
     a.divWo = make_fastdiv((uint32_t)Wo);
-    if (BN == 128 && BK == 64) launch_igemm<128, 128, 64, 2>(a, stream);
-    else if (BN == 128 && BK == 32) launch_igemm<128, 128, 32, 2>(a, stream);
-    else if (BN == 64 && BK == 64) launch_igemm<128, 64, 64, 2>(a, stream);
-    else if (BN == 64 && BK == 32) launch_igemm<128, 64, 32, 2>(a, stream);
-    else if (BN == 32 && BK == 64) launch_igemm<128, 32, 64, 4>(a, stream);
-    else launch_igemm<128, 32, 32, 4>(a, stream);
+    // Defaults from A/B timing on MI355X (tools/conv_bench.py): a two-stage ring
+    // with three or four resident workgroups per CU beats deeper rings at one
+    // workgroup per CU on every layer shape of the network.
+    const int ns = env_int("YOLO_AMD_CONV_NSTAGE", 2);
+    if (BN == 128 && BK == 64) {
+        if (ns == 3) launch_igemm<128, 128, 64, 2, 3>(a, stream);
+        else if (ns == 4) launch_igemm<128, 128, 64, 2, 4>(a, stream);
+        else launch_igemm<128, 128, 64, 2, 2>(a, stream);
+    } else if (BN == 128 && BK == 32) {
+        if (ns == 4) launch_igemm<128, 128, 32, 2, 4>(a, stream);
+        else if (ns == 5) launch_igemm<128, 128, 32, 2, 5>(a, stream);
+        else launch_igemm<128, 128, 32, 2, 2>(a, stream);
+    } else if (BN == 64 && BK == 64) {
+        if (ns == 4) launch_igemm<128, 64, 64, 2, 4>(a, stream);
+        else launch_igemm<128, 64, 64, 2, 2>(a, stream);
+    } else if (BN == 64 && BK == 32) {
+        if (ns == 4) launch_igemm<128, 64, 32, 2, 4>(a, stream);
+        else launch_igemm<128, 64, 32, 2, 2>(a, stream);
+    } else if (BN == 32 && BK == 64) {
+        if (ns == 4) launch_igemm<128, 32, 64, 4, 4>(a, stream);
+        else launch_igemm<128, 32, 64, 4, 2>(a, stream);
+    } else {
+        launch_igemm<128, 32, 32, 4, 2>(a, stream);
+    }
     return YA_OK;
 }
 

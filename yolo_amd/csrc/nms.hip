@@ -1,6 +1,6 @@
 // Confidence filter + per-class greedy NMS (filter_results) and box_iou for
 // gfx950.  Restates /root/reference/utilis.py:298-323 (box_iou), :355-390
-// (filter_img_class) and :393-465 (filter_results) as five small kernels:
+// (filter_img_class) and :393-465 (filter_results) as six small kernels:
 //
 //   compact  : stream the (B,N,D) tensor once through LDS; for every row with
 //              objectness > conf compute corners, first-index class argmax and
@@ -8,8 +8,13 @@
 //   sort     : one workgroup per image, LDS bitonic sort of the keys
 //              (class asc, objectness desc, original row asc) and segment
 //              boundaries per (image, class)
-//   suppress : one wave per (image, class) segment, greedy suppression in
-//              64-box chunks (IoU in the reference's fp32 operation order)
+//   mask     : 64x64 tiles of the per-segment suppression matrix, one wave per
+//              tile, spread over the whole GPU: bit j of word (i, w) says box
+//              64w+j (later in the visiting order) is suppressed by box i
+//              (IoU in the reference's fp32 operation order)
+//   reduce   : one workgroup per (image, class) segment walks the boxes in
+//              order, 64 at a time: resolves the diagonal word serially, then
+//              ORs the rows of the survivors into the "removed" bit vector
 //   scan     : exclusive scan of kept counts -> output row offsets, total K
 //   gather   : write the (K, 9) rows
 //
@@ -161,7 +166,8 @@ __device__ __forceinline__ void bitonic_sort(Ptr s, int P) {
 __global__ void __launch_bounds__(SORT_THREADS)
 nms_sort_kernel(const int* __restrict__ cand_count, int key_stride, int C,
                 unsigned long long* __restrict__ keys, int* __restrict__ seg_start,
-                int* __restrict__ seg_end) {
+                int* __restrict__ seg_end, int* __restrict__ tile_base, int* __restrict__ mask_off,
+                int* __restrict__ total_tiles) {
     __shared__ unsigned long long skeys[SORT_LDS_KEYS];
     const int b = blockIdx.x;
     const int cnt = cand_count[b];
@@ -170,7 +176,10 @@ nms_sort_kernel(const int* __restrict__ cand_count, int key_stride, int C,
         seg_start[b * C + c] = 0;
         seg_end[b * C + c] = 0;
     }
-    if (cnt == 0) return;
+    if (cnt == 0) {
+        if (threadIdx.x == 0) total_tiles[b] = 0;
+        return;
+    }
     int P = 1;
     while (P < cnt) P <<= 1;
     const unsigned long long* sorted;
@@ -197,68 +206,179 @@ nms_sort_kernel(const int* __restrict__ cand_count, int key_stride, int C,
         if (i == 0 || key_cls(sorted[i - 1]) != c) seg_start[b * C + c] = i;
         if (i == cnt - 1 || key_cls(sorted[i + 1]) != c) seg_end[b * C + c] = i + 1;
     }
+    // Plan the suppression-matrix tiles: a segment of n boxes has T = ceil(n/64)
+    // word columns, T(T+1)/2 upper-triangular tiles and n*T mask words.
+    // Exclusive prefix sums over the classes give every segment its first tile
+    // number and its mask offset.  (skeys is free now and serves as scratch.)
+    __syncthreads();
+    int* sa = reinterpret_cast<int*>(skeys);
+    int* sb = sa + SORT_THREADS;
+    int carry_t = 0, carry_w = 0;
+    for (int c0 = 0; c0 < C; c0 += SORT_THREADS) {
+        const int c = c0 + threadIdx.x;
+        int tiles = 0, words = 0;
+        if (c < C) {
+            const int n = seg_end[b * C + c] - seg_start[b * C + c];
+            const int T = (n + 63) >> 6;
+            tiles = T * (T + 1) / 2;
+            words = n * T;
+        }
+        sa[threadIdx.x] = tiles;
+        sb[threadIdx.x] = words;
+        __syncthreads();
+        for (int d = 1; d < SORT_THREADS; d <<= 1) {
+            int va = 0, vb = 0;
+            if ((int)threadIdx.x >= d) { va = sa[threadIdx.x - d]; vb = sb[threadIdx.x - d]; }
+            __syncthreads();
+            sa[threadIdx.x] += va;
+            sb[threadIdx.x] += vb;
+            __syncthreads();
+        }
+        if (c < C) {
+            tile_base[b * C + c] = carry_t + sa[threadIdx.x] - tiles;
+            mask_off[b * C + c] = carry_w + sb[threadIdx.x] - words;
+        }
+        carry_t += sa[SORT_THREADS - 1];
+        carry_w += sb[SORT_THREADS - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total_tiles[b] = carry_t;
 }
 
-// ---------------------------------------------------------------- suppress
-// One wave per (image, class).  Boxes are visited in sorted order in chunks of
-// 64 (one per lane).  A chunk is first tested against every box kept from
-// earlier chunks, then resolved internally pivot by pivot.  A box survives iff
-// `iou < thresh` holds against every earlier kept box, so iou >= thresh and
-// NaN both suppress (utilis.py:379-385).
-constexpr int KEPT_LDS = 1024;           // kept boxes cached in LDS per segment
+// ---------------------------------------------------------------- mask
+// One wave per 64x64 tile (ti <= tj) of a segment's suppression matrix.
+// Lane = row box i = 64*ti + lane; the 64 column boxes go through LDS.
+// Bit jj of the word: box j = 64*tj + jj comes later than i in the visiting
+// order and `iou(i, j) < thresh` is false (so iou >= thresh or NaN), which is
+// when the reference zeroes row j while box i is the pivot (utilis.py:379-381).
+// Off-diagonal words land in mask[i][tj] (row-major, T words per row), the
+// diagonal words in their own contiguous array.
+constexpr int MASK_GRID_X = 256;
 
-__global__ void __launch_bounds__(64)
-nms_suppress_kernel(const unsigned long long* __restrict__ keys, int key_stride, int N, int C,
-                    const int* __restrict__ seg_start, const int* __restrict__ seg_end,
-                    const float4* __restrict__ boxes, int box_stride, float thresh,
-                    int* __restrict__ kept_pos, int* __restrict__ seg_kept) {
-    __shared__ float4 kept_box[KEPT_LDS];
-    __shared__ float4 chunk_box[64];
-    const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-    const int s = seg_start[b * C + c], e = seg_end[b * C + c];
-    const int n = e - s;
+__global__ void __launch_bounds__(256)
+nms_mask_kernel(const unsigned long long* __restrict__ keys, int key_stride, int N, int C,
+                const int* __restrict__ seg_start, const int* __restrict__ seg_end,
+                const int* __restrict__ tile_base, const int* __restrict__ mask_off,
+                const int* __restrict__ total_tiles, const float4* __restrict__ boxes, int box_stride,
+                float thresh, unsigned long long* __restrict__ mask, size_t mask_stride,
+                unsigned long long* __restrict__ diag) {
+    __shared__ float4 colbox[4][64];
+    const int b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nt = total_tiles[b];
+    const unsigned long long* gkb = keys + (size_t)b * key_stride;
+    const float4* gb = boxes + (size_t)b * N * box_stride;
+    for (int q = blockIdx.x * 4 + wave; q < nt; q += gridDim.x * 4) {
+        // segment that owns tile q: the last class whose first tile is <= q
+        int lo = 0, hi = C - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tile_base[b * C + mid] <= q) lo = mid; else hi = mid - 1;
+        }
+        const int c = lo;
+        const int s = seg_start[b * C + c];
+        const int n = seg_end[b * C + c] - s;
+        const int T = (n + 63) >> 6;
+        int rem = q - tile_base[b * C + c], ti = 0;
+        while (rem >= T - ti) { rem -= T - ti; ++ti; }
+        const int tj = ti + rem;
+        const int i = ti * 64 + lane, j0 = tj * 64;
+        float4 mine = make_float4(0.f, 0.f, 0.f, 0.f), col = mine;
+        if (i < n) mine = gb[(size_t)key_row(gkb[s + i]) * box_stride];
+        if (j0 + lane < n) col = gb[(size_t)key_row(gkb[s + j0 + lane]) * box_stride];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier reads of colbox are done
+        __builtin_amdgcn_wave_barrier();
+        colbox[wave][lane] = col;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int ncol = min(64, n - j0);
+        unsigned long long word = 0;
+        for (int jj = 0; jj < ncol; ++jj) {
+            const float4 cb = colbox[wave][jj];
+            bool sup = !(iou_ref(mine, cb) < thresh);
+            if (ti == tj) sup = sup && (jj > lane);
+            word |= (unsigned long long)sup << jj;
+        }
+        if (i < n) {
+            if (ti == tj) diag[(size_t)b * N + s + i] = word;
+            else mask[(size_t)b * mask_stride + mask_off[b * C + c] + (size_t)i * T + tj] = word;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- reduce
+// One workgroup (4 waves) per (image, class).  `removed` holds one bit per box
+// of the segment.  For each group of 64 boxes in visiting order, wave 0
+// resolves the group serially with the diagonal words (a box survives iff its
+// bit is still clear, and then sets the bits of the boxes it suppresses inside
+// the group); then all waves OR the mask rows of the survivors into the words
+// of the later groups.  A box survives iff `iou < thresh` held against every
+// earlier survivor: the reference's greedy loop (utilis.py:367-385).
+constexpr int REDUCE_MAX_WORDS = 512;    // 32768 boxes per segment
+
+__global__ void __launch_bounds__(256)
+nms_reduce_kernel(int N, int C, const int* __restrict__ seg_start, const int* __restrict__ seg_end,
+                  const int* __restrict__ mask_off, const unsigned long long* __restrict__ mask,
+                  size_t mask_stride, const unsigned long long* __restrict__ diag,
+                  int* __restrict__ kept_pos, int* __restrict__ seg_kept) {
+    __shared__ unsigned long long removed[REDUCE_MAX_WORDS];
+    __shared__ unsigned long long kbits;
+    const int c = blockIdx.x, b = blockIdx.y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = seg_start[b * C + c];
+    const int n = seg_end[b * C + c] - s;
     if (n <= 0) {
-        if (lane == 0) seg_kept[b * C + c] = 0;
+        if (threadIdx.x == 0) seg_kept[b * C + c] = 0;
         return;
     }
-    const unsigned long long* gk = keys + (size_t)b * key_stride + s;
-    const float4* gb = boxes + (size_t)b * N * box_stride;
-    int* kp = kept_pos + (size_t)b * N + s;   // kept sorted positions, segment-local order
+    const int T = (n + 63) >> 6;
+    const unsigned long long* rows = mask + (size_t)b * mask_stride + mask_off[b * C + c];
+    const unsigned long long* dg = diag + (size_t)b * N + s;
+    int* kp = kept_pos + (size_t)b * N + s;
+    for (int w = threadIdx.x; w < T; w += 256) removed[w] = 0;
+    __syncthreads();
     int nk = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int idx = base + lane;
-        bool alive = idx < n;
-        float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (alive) mine = gb[(size_t)key_row(gk[idx]) * box_stride];
-        chunk_box[lane] = mine;
-        // against boxes kept from earlier chunks
-        for (int k = 0; k < nk; ++k) {
-            float4 kb = (k < KEPT_LDS) ? kept_box[k] : gb[(size_t)key_row(gk[kp[k]]) * box_stride];
-            if (alive && !(iou_ref(kb, mine) < thresh)) alive = false;
-            if ((k & 15) == 15 && __ballot(alive) == 0) break;
+    unsigned long long d_next = (wave == 0 && lane < n) ? dg[lane] : 0;
+    for (int g = 0; g < T; ++g) {
+        if (wave == 0) {
+            const unsigned long long d = d_next;
+            const int nidx = (g + 1) * 64 + lane;
+            d_next = (g + 1 < T && nidx < n) ? dg[nidx] : 0;          // prefetch the next group
+            const int left = n - g * 64;
+            const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            unsigned long long cur = removed[g] | ~valid;
+            unsigned long long keep = 0;
+            while (~cur) {
+                const int i = __ffsll((long long)~cur) - 1;
+                const unsigned int dlo = __builtin_amdgcn_readlane((unsigned int)d, i);
+                const unsigned int dhi = __builtin_amdgcn_readlane((unsigned int)(d >> 32), i);
+                keep |= 1ull << i;
+                cur |= (1ull << i) | ((unsigned long long)dhi << 32) | dlo;
+            }
+            if ((keep >> lane) & 1ull) kp[nk + __popcll(keep & ((1ull << lane) - 1ull))] = g * 64 + lane;
+            if (lane == 0) kbits = keep;
         }
         __syncthreads();
-        // inside the chunk, pivot by pivot
-        unsigned long long m = __ballot(alive);
-        while (m) {
-            const int i = __ffsll((long long)m) - 1;
-            float4 pb = chunk_box[i];
-            if (lane > i && alive && !(iou_ref(pb, mine) < thresh)) alive = false;
-            m = __ballot(alive);
-            m = (i >= 63) ? 0ull : (m & ~((2ull << i) - 1ull));
+        const unsigned long long keep = kbits;
+        const int nwords = T - g - 1;
+        if (nwords > 0) {
+            // wave w takes the survivors number w, w+4, ... of this group
+            unsigned long long m = keep;
+            for (int k = 0; k < wave && m; ++k) m &= m - 1;
+            while (m) {
+                const int i = __ffsll((long long)m) - 1;
+                const unsigned long long* row = rows + (size_t)(g * 64 + i) * T + (g + 1);
+                for (int w = lane; w < nwords; w += 64) {
+                    const unsigned long long v = row[w];
+                    if (v) atomicOr(&removed[g + 1 + w], v);
+                }
+                for (int k = 0; k < 4 && m; ++k) m &= m - 1;
+            }
         }
-        // append survivors
-        m = __ballot(alive);
-        if (alive) {
-            const int r = nk + __popcll(m & ((1ull << lane) - 1ull));
-            if (r < KEPT_LDS) kept_box[r] = mine;
-            kp[r] = idx;
-        }
-        nk += __popcll(m);
-        __threadfence_block();
+        nk += __popcll(keep);
         __syncthreads();
     }
-    if (lane == 0) seg_kept[b * C + c] = nk;
+    if (threadIdx.x == 0) seg_kept[b * C + c] = nk;
 }
 
 // ---------------------------------------------------------------- scan
@@ -367,6 +487,12 @@ struct NmsWorkspace {
     float4* boxes;       // [B][N]
     float* scores;       // [B][N]
     int* kept_pos;       // [B][N]
+    int* tile_base;      // [B*C] first tile number of each segment
+    int* mask_off;       // [B*C] first mask word of each segment (inside the image's region)
+    int* total_tiles;    // [B]
+    unsigned long long* diag;   // [B][N] diagonal words of the suppression matrices
+    unsigned long long* mask;   // [B][mask_stride] off-diagonal words, row-major per segment
+    size_t mask_stride;
     int key_stride;
     size_t bytes;
     size_t zero_bytes;   // leading region that must be zeroed before every call
@@ -390,6 +516,13 @@ static NmsWorkspace carve(void* base, int B, int N, int C) {
     w.boxes = (float4*)take(sizeof(float4) * (size_t)B * N);
     w.scores = (float*)take(sizeof(float) * (size_t)B * N);
     w.kept_pos = (int*)take(sizeof(int) * (size_t)B * N);
+    w.tile_base = (int*)take(sizeof(int) * S);
+    w.mask_off = (int*)take(sizeof(int) * S);
+    w.total_tiles = (int*)take(sizeof(int) * (size_t)B);
+    w.diag = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)B * N);
+    // sum over segments of n * ceil(n/64) <= N*N/64 + N words per image
+    w.mask_stride = ((size_t)N * N + 63) / 64 + (size_t)N;
+    w.mask = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)B * w.mask_stride);
     w.bytes = off;
     return w;
 }
@@ -410,7 +543,8 @@ extern "C" int yolo_amd_filter_results(const float* pred, int B, int N, int D, i
     YA_REQUIRE(pred && workspace && out_rows && out_count, "filter_results: null pointer");
     YA_REQUIRE(B > 0 && N > 0 && C > 0, "filter_results: B, N, C must be positive (got %d, %d, %d)", B, N, C);
     YA_REQUIRE(D >= 5 + C, "filter_results: D=%d is smaller than 5 + C=%d", D, 5 + C);
-    YA_REQUIRE(N < (1 << KEY_ROW_BITS), "filter_results: N=%d exceeds the %d-bit row field", N, KEY_ROW_BITS);
+    YA_REQUIRE(N <= REDUCE_MAX_WORDS * 64, "filter_results: N=%d exceeds %d boxes per image", N,
+               REDUCE_MAX_WORDS * 64);
     YA_REQUIRE(C < (1 << (64 - KEY_CLS_SHIFT)), "filter_results: C=%d exceeds the class field", C);
     YA_REQUIRE(((uintptr_t)pred & 3) == 0 && ((uintptr_t)workspace & 255) == 0,
                "filter_results: pred must be 4-byte and workspace 256-byte aligned");
@@ -435,9 +569,13 @@ extern "C" int yolo_amd_filter_results(const float* pred, int B, int N, int D, i
                            conf, w.key_stride, w.cand_count, w.keys, w.boxes, w.scores);
     }
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(SORT_THREADS), 0, stream, w.cand_count,
-                       w.key_stride, C, w.keys, w.seg_start, w.seg_end);
-    hipLaunchKernelGGL(nms_suppress_kernel, dim3(C, B), dim3(64), 0, stream, w.keys, w.key_stride, N, C,
-                       w.seg_start, w.seg_end, w.boxes, 1, nms_thresh, w.kept_pos, w.seg_kept);
+                       w.key_stride, C, w.keys, w.seg_start, w.seg_end, w.tile_base, w.mask_off,
+                       w.total_tiles);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, B), dim3(256), 0, stream, w.keys, w.key_stride,
+                       N, C, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles, w.boxes, 1,
+                       nms_thresh, w.mask, w.mask_stride, w.diag);
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(C, B), dim3(256), 0, stream, N, C, w.seg_start, w.seg_end,
+                       w.mask_off, w.mask, w.mask_stride, w.diag, w.kept_pos, w.seg_kept);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, B * C, w.seg_off,
                        out_count);
     hipLaunchKernelGGL(nms_gather_kernel, dim3(C, B), dim3(64), 0, stream, w.keys, w.key_stride, N, C,
@@ -457,7 +595,7 @@ extern "C" int yolo_amd_filter_img_class(const float* rows8, int m, float cls, f
                                          int* out_count, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     YA_REQUIRE(rows8 && workspace && out_rows8 && out_count, "filter_img_class: null pointer");
-    YA_REQUIRE(m > 0 && m < (1 << KEY_ROW_BITS), "filter_img_class: m=%d out of range", m);
+    YA_REQUIRE(m > 0 && m <= REDUCE_MAX_WORDS * 64, "filter_img_class: m=%d out of range", m);
     YA_REQUIRE(((uintptr_t)rows8 & 15) == 0 && ((uintptr_t)out_rows8 & 15) == 0 &&
                    ((uintptr_t)workspace & 255) == 0,
                "filter_img_class: rows must be 16-byte and workspace 256-byte aligned");
@@ -470,10 +608,13 @@ extern "C" int yolo_amd_filter_img_class(const float* rows8, int m, float cls, f
     hipLaunchKernelGGL(rows8_keys_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, rows8, m, cls,
                        w.cand_count, w.keys);
     hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(SORT_THREADS), 0, stream, w.cand_count,
-                       w.key_stride, 1, w.keys, w.seg_start, w.seg_end);
-    hipLaunchKernelGGL(nms_suppress_kernel, dim3(1, 1), dim3(64), 0, stream, w.keys, w.key_stride, m, 1,
-                       w.seg_start, w.seg_end, reinterpret_cast<const float4*>(rows8), 2, nms_thresh,
-                       w.kept_pos, w.seg_kept);
+                       w.key_stride, 1, w.keys, w.seg_start, w.seg_end, w.tile_base, w.mask_off,
+                       w.total_tiles);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, 1), dim3(256), 0, stream, w.keys, w.key_stride,
+                       m, 1, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles,
+                       reinterpret_cast<const float4*>(rows8), 2, nms_thresh, w.mask, w.mask_stride, w.diag);
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1, 1), dim3(256), 0, stream, m, 1, w.seg_start, w.seg_end,
+                       w.mask_off, w.mask, w.mask_stride, w.diag, w.kept_pos, w.seg_kept);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, 1, w.seg_off,
                        out_count);
     hipLaunchKernelGGL(rows8_gather_kernel, dim3(min(256, (m + 63) / 64)), dim3(64), 0, stream, w.keys,
