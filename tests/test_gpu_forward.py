@@ -116,6 +116,46 @@ def test_conv_layer(case):
         torch.testing.assert_close(got, want, rtol=1.0 / 128, atol=1.0 / 128)
 
 
+# stride-1 3x3 layers on 13*2^n maps take the patch-reuse kernel; both of its
+# workgroup shapes (one or two spatial tiles) are forced in turn
+PATCH_CASES = [
+    # name, B, H, cin, cout, leaky, residual, fp32_out
+    ("p3_c32_n128_short_k", 1, 13, 32, 128, True, False, False),
+    ("p3_c64_n128_b3", 3, 26, 64, 128, True, True, False),
+    ("p3_c96_n256_one_tile", 1, 13, 96, 256, True, True, False),
+    ("p3_c256_n512_h26", 2, 26, 256, 512, True, True, False),
+    ("p3_c128_n255_fp32", 2, 13, 128, 255, False, False, True),
+    ("p3_c64_n128_h52", 1, 52, 64, 128, True, False, False),
+]
+
+
+@pytest.mark.parametrize("tiles", [1, 2])
+@pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: c[0])
+def test_conv3x3_patch_kernel(case, tiles, monkeypatch):
+    from gpu_helpers import conv_reference, run_conv
+    name, B, H, cin, cout, leaky, use_res, fp32_out = case
+    monkeypatch.setenv("YOLO_AMD_CONV3_TILES", str(tiles))
+    r = gi.rs(abs(hash(name)) % 10000 + tiles)
+    x0 = torch.from_numpy(r.standard_normal((B, H, H, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    w = torch.from_numpy((r.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
+    bias = torch.from_numpy(r.normal(0, 0.3, cout).astype(np.float32))
+    res = None
+    if use_res:
+        res = torch.from_numpy(r.standard_normal((B, H, H, cout)).astype(np.float32)).cuda().to(torch.bfloat16)
+    got = run_conv(x0, w, bias, leaky=leaky, residual=res, fp32_out=fp32_out).float().cpu()
+    want = conv_reference(x0, w, bias, leaky=leaky, residual=res)
+    assert torch.isfinite(got).all(), "output holds NaN/inf (unwritten elements?)"
+    # and the generic im2col kernel must agree with it
+    monkeypatch.setenv("YOLO_AMD_CONV3", "0")
+    generic = run_conv(x0, w, bias, leaky=leaky, residual=res, fp32_out=fp32_out).float().cpu()
+    if fp32_out:
+        torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(got, generic, rtol=2e-4, atol=2e-4)
+    else:
+        torch.testing.assert_close(got, want, rtol=1.0 / 128, atol=1.0 / 128)
+        torch.testing.assert_close(got, generic, rtol=1.0 / 128, atol=1.0 / 128)
+
+
 def test_first_layer():
     from yolo_amd import _lib
     from yolo_amd._lib import ConvDesc, lib, check

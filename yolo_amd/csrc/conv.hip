@@ -47,9 +47,87 @@ struct ConvArgs {
     FastDiv divHoWo, divWo;
 };
 
+
 __device__ __forceinline__ void lds_dma16(const __bf16* gsrc, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------- tile epilogue through LDS
+// The accumulator layout (one pixel x 4 channels per lane) gives 8-byte stores
+// scattered over 16 rows, and a residual that is loaded just before it is
+// needed costs one memory round trip per accumulator tile.  Instead the
+// workgroup's output tile goes through LDS (free once the K loop is done):
+//   1. the residual tile is copied in by LDS-DMA (no registers, every load in
+//      flight at once);
+//   2. each lane adds its accumulators (+bias, LeakyReLU) to the residual it
+//      finds there in fp32, rounds ONCE to bf16 and writes back in place;
+//   3. the tile is written out with 16-byte coalesced stores.
+// Tile image: NSLOT rows (pixels) of BNT bf16, no padding (LDS-DMA writes 1 KiB
+// runs); the 16-byte chunk c of row r sits at chunk position c ^ (r mod CH8),
+// which spreads the per-lane 8-byte accesses of step 2 (16 rows, same channel)
+// over the banks.
+template <int BNT>
+__device__ __forceinline__ int tile_addr(int row, int chl) {
+    constexpr int CH8 = BNT / 8;
+    const int c = chl >> 3;
+    return row * (BNT * 2) + ((c ^ (row & (CH8 - 1))) << 4) + ((chl & 7) << 1);
+}
+
+template <int NSLOT, int BNT, int NT, typename PixFn>
+__device__ __forceinline__ void tile_load_residual(char* lds, const __bf16* __restrict__ res,
+                                                   const __bf16* zero, int Cout, int n0, int w,
+                                                   int lane, PixFn pix) {
+    constexpr int CH8 = BNT / 8, RPI = 64 / CH8;         // rows per wave-instruction
+    constexpr int NINST = (NSLOT * CH8 + 63) / 64, NWAVE = NT / 64;
+#pragma unroll
+    for (int i = 0; i < (NINST + NWAVE - 1) / NWAVE; ++i) {
+        const int j = w + i * NWAVE;
+        if (j < NINST) {
+            const int row = j * RPI + lane / CH8;
+            const int c = (lane % CH8) ^ (row & (CH8 - 1));
+            const __bf16* src = zero;
+            if (row < NSLOT && n0 + c * 8 < Cout) {
+                const long long m = pix(row);
+                if (m >= 0) src = res + (size_t)m * Cout + n0 + c * 8;
+            }
+            lds_dma16(src, lds + j * 1024);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NSLOT, int BNT, int NT, typename PixFn>
+__device__ __forceinline__ void tile_store(const char* lds, __bf16* __restrict__ dst, int Cout, int n0,
+                                           PixFn pix) {
+    constexpr int CH8 = BNT / 8, ITEMS = NSLOT * CH8, IT = (ITEMS + NT - 1) / NT;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = threadIdx.x + i * NT;
+        const int slot = e / CH8, c8 = e - slot * CH8;
+        if (e < ITEMS && n0 + c8 * 8 < Cout) {
+            const long long m = pix(slot);
+            if (m >= 0)
+                *reinterpret_cast<bf16x8*>(dst + (size_t)m * Cout + n0 + c8 * 8) =
+                    *reinterpret_cast<const bf16x8*>(lds + tile_addr<BNT>(slot, c8 * 8));
+        }
+    }
+}
+
+// lane-side step: v[4] (bias and activation applied) for tile row `slot`,
+// tile channel `chl`; adds the parked residual, rounds once, writes in place
+template <int BNT>
+__device__ __forceinline__ void tile_put(char* lds, int slot, int chl, float v[4], bool has_res) {
+    bf16x4* p = reinterpret_cast<bf16x4*>(lds + tile_addr<BNT>(slot, chl));
+    if (has_res) {
+        const bf16x4 rr = *p;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+    }
+    bf16x4 pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[e];
+    *p = pk;
 }
 
 template <int N>
@@ -90,7 +168,9 @@ conv_igemm_kernel(const ConvArgs a) {
     static_assert(WMP % 16 == 0 && WNC % 16 == 0, "wave tile must be a multiple of 16x16");
     static_assert(NSTAGE >= 2 && (PRE - 1) * (NA + NB) < 64, "vmcnt holds 6 bits");
 
-    __shared__ __attribute__((aligned(1024))) char lds[NSTAGE * STAGE];
+    constexpr int EPI_BYTES = BM * BN * 2;
+    constexpr int LDS_BYTES = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -243,6 +323,34 @@ conv_igemm_kernel(const ConvArgs a) {
 
     // ---- epilogue: bias, LeakyReLU, residual, store
     const int px = lane & 15, cq = (lane >> 4) * 4;
+    if (!a.dst_fp32 && (a.Cout & 7) == 0) {
+        auto pix = [&](int slot) -> long long { return m0 + slot < a.M ? (long long)(m0 + slot) : -1; };
+        __syncthreads();                       // operand stages are dead from here on
+        if (a.res) {
+            tile_load_residual<BM, BN, 256>(lds, a.res, a.zero, a.Cout, n0, w, lane, pix);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int tp = 0; tp < TP; ++tp) {
+            const int slot = wm * WMP + tp * 16 + px;
+#pragma unroll
+            for (int tc = 0; tc < TC; ++tc) {
+                const int chl = wn * WNC + tc * 16 + cq;
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + chl);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[tc][tp][r] + bs[r];
+                    if (a.leaky) x = x > 0.f ? x : 0.1f * x;
+                    v[r] = x;
+                }
+                tile_put<BN>(lds, slot, chl, v, a.res != nullptr);
+            }
+        }
+        __syncthreads();
+        tile_store<BM, BN, 256>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
+        return;
+    }
     const bool vec = (a.Cout & 3) == 0;
 #pragma unroll
     for (int tp = 0; tp < TP; ++tp) {
@@ -284,6 +392,275 @@ conv_igemm_kernel(const ConvArgs a) {
                     if (a.dst_fp32) ((float*)a.dst)[o + r] = x;
                     else ((__bf16*)a.dst)[o + r] = (__bf16)x;
                 }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- 3x3 with patch reuse
+// Stride-1 3x3 layers re-read every input pixel nine times when each tap is
+// staged as its own im2col tile, and the CU's vector-memory path (not the
+// MFMA pipe) becomes the limit.  This kernel stages, per 32-channel chunk, the
+// (13+2)x(13+2) input PATCH of a 13x13 output tile once and feeds all nine
+// taps from it, so only the weights are streamed per tap:
+//   bytes filled per chunk  = 14 KB patch + 9 x 8 KB weights   (was 9 x 16 KB)
+// and with two spatial tiles per workgroup the weight stream is shared too.
+//
+// Workgroup = TILES spatial tiles x 128 output channels, 4*TILES waves; wave
+// (t, cg) owns all 11 pixel groups (176 slots for the 169 pixels) of tile t for
+// channels cg*32..+32.
+//   patch   LDS planes [q = 16-byte chunk 0..3][row 0..15][16 slots], slot of
+//           patch pixel (py, px) = (px + 13*py) mod 16 in row py: for every tap
+//           the 16 lanes of a pixel group then read 16 distinct bank slots.
+//           Filled through registers (coalesced 64-byte pixel reads, then
+//           ds_write), double buffered, loads issued two K-iterations early.
+//   weights LDS-DMA ring of (chunk, kw) stages = 3 taps (kh) x 128 channels x
+//           32 k, XOR-swizzled rows as in conv_layout.h, counted vmcnt waits.
+// 13 divides every feature-map side of a 416-pixel input (13 * 2^n).
+constexpr int P3_TS = 13;                  // spatial tile side
+constexpr int P3_NPIX = P3_TS * P3_TS;     // 169 output pixels per tile
+constexpr int P3_TP = 11;                  // pixel groups of 16 (176 slots)
+constexpr int P3_PLANE = 256 * 16;         // bytes per patch plane (16 rows x 16 slots x 16 B)
+constexpr int P3_PATCH = 4 * P3_PLANE;     // 16 KiB per (tile, buffer)
+constexpr int P3_WSTAGE = 3 * 128 * 64;    // 24 KiB: 3 taps x 128 channels x 32 bf16
+
+struct Conv3Args {
+    const __bf16* src;
+    const __bf16* wgt;
+    const float* bias;
+    const __bf16* res;
+    void* dst;
+    const __bf16* zero;
+    int C, H, W, Cout, K;
+    int leaky, dst_fp32;
+    int tiles_y, tiles_x, ntiles;      // spatial tiles per image (y, x) and in the batch
+    int tiles_m, tiles_n;              // workgroup grid: tile groups x channel tiles
+};
+
+template <int X>
+__device__ __forceinline__ void p3_wait() { wait_vmcnt<X>(); }
+
+template <int TILES>
+__global__ void __launch_bounds__(256 * TILES)
+conv3x3_patch_kernel(const Conv3Args a) {
+    constexpr int NW = 4 * TILES;              // waves
+    constexpr int NSTG = TILES == 2 ? 3 : 2;   // weight ring depth
+    constexpr int PRE = NSTG - 1;
+    constexpr int LW = 24 / NW;                // weight LDS-DMA instructions per wave per stage
+    constexpr int LP = 4;                      // patch loads per wave per chunk
+    constexpr int PATCH_TOTAL = 2 * TILES * P3_PATCH;
+    __shared__ __attribute__((aligned(1024))) char lds[PATCH_TOTAL + NSTG * P3_WSTAGE];
+    char* wring = lds + PATCH_TOTAL;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = w >> 2, cg = w & 3;
+
+    int tile;
+    {
+        const int T = a.tiles_m * a.tiles_n;
+        const int q8 = T >> 3, r8 = T & 7;
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    }
+    const int tile_n = tile % a.tiles_n, tb = tile / a.tiles_n;
+    const int n0 = tile_n * 128;
+    const int per_img = a.tiles_y * a.tiles_x;
+
+    // ---- the spatial tile this wave computes
+    const int gt = tb * TILES + t;
+    const bool tvalid = gt < a.ntiles;
+    int cb = 0, oy0 = 0, ox0 = 0;
+    if (tvalid) {
+        cb = gt / per_img;
+        const int rem = gt - cb * per_img;
+        const int tyi = rem / a.tiles_x;
+        oy0 = tyi * P3_TS;
+        ox0 = (rem - tyi * a.tiles_x) * P3_TS;
+    }
+    const int r = lane & 15, q = lane >> 4;
+    int tyb[P3_TP];                            // byte offset of (plane q, patch row ty) per pixel group
+#pragma unroll
+    for (int tp = 0; tp < P3_TP; ++tp) {
+        const int p = min(tp * 16 + r, P3_NPIX - 1);
+        tyb[tp] = q * P3_PLANE + (p / P3_TS) * 256;
+    }
+    const int wfrag = slot_of<32>(r, q) * 16;
+
+    // ---- patch fill: LP rows (of 16 pixels x 4 chunks) per wave per chunk
+    const int fpx = lane >> 2, fq = lane & 3;
+    int poff[LP], pdst[LP];
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        const int j = w + i * NW;              // row number across the TILES patches
+        const int tf = j >> 4, py = j & 15;
+        const int gtf = tb * TILES + tf;
+        int off = -1;
+        if (tf < TILES && gtf < a.ntiles && py < P3_TS + 2 && fpx < P3_TS + 2) {
+            const int fb = gtf / per_img;
+            const int rem = gtf - fb * per_img;
+            const int tyi = rem / a.tiles_x;
+            const int iy = tyi * P3_TS - 1 + py;
+            const int ix = (rem - tyi * a.tiles_x) * P3_TS - 1 + fpx;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) off = ((fb * a.H + iy) * a.W + ix) * a.C + fq * 8;
+        }
+        poff[i] = off;
+        pdst[i] = (tf < TILES ? tf : 0) * P3_PATCH + fq * P3_PLANE + (py * 16 + ((fpx + P3_TS * py) & 15)) * 16;
+    }
+    // ---- weight fill: LW LDS-DMA instructions per wave per (chunk, kw) stage
+    int woff[LW];
+    {
+        const int qw = (lane & 3) ^ chunk_swizzle<32>(lane >> 2);
+#pragma unroll
+        for (int i = 0; i < LW; ++i) {
+            const int j = w + i * NW;          // 0..23: kh = j / 8, 16 channel rows each
+            const int kh = j >> 3, n = (j & 7) * 16 + (lane >> 2);
+            woff[i] = (n0 + n) * a.K + kh * 3 * a.C + qw * 8;
+        }
+    }
+    auto issue_w = [&](int it) {               // stage `it` = (chunk it/3, kw it%3)
+        const int chunk = it / 3, kw = it - chunk * 3;
+        const int delta = kw * a.C + chunk * 32;
+        char* dst = wring + (it % NSTG) * P3_WSTAGE;
+#pragma unroll
+        for (int i = 0; i < LW; ++i) lds_dma16(a.wgt + (woff[i] + delta), dst + (w + i * NW) * 1024);
+    };
+    bf16x8 preg[LP];
+    auto load_patch = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < LP; ++i) {
+            const __bf16* p = poff[i] >= 0 ? a.src + (poff[i] + chunk * 32) : a.zero;
+            preg[i] = *reinterpret_cast<const bf16x8*>(p);
+        }
+    };
+    auto store_patch = [&](int buf) {
+        char* base = lds + buf * (TILES * P3_PATCH);
+#pragma unroll
+        for (int i = 0; i < LP; ++i) *reinterpret_cast<bf16x8*>(base + pdst[i]) = preg[i];
+    };
+
+    f32x4 acc[2][P3_TP];
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+        for (int tp = 0; tp < P3_TP; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int NCH = a.C / 32, KI = NCH * 3;
+    load_patch(0);
+    store_patch(0);
+#pragma unroll
+    for (int s = 0; s < PRE; ++s)
+        if (s < KI) issue_w(s);
+
+    int chunk = 0, kw = 0;
+    for (int it = 0; it < KI; ++it) {
+        // loads younger than weight stage `it`: later weight stages already
+        // issued, and the patch loads issued (after the weight stage) at kw == 0
+        // inside the last PRE iterations
+        const int nW = min(PRE - 1, KI - 1 - it);
+        bool nP = false;
+#pragma unroll
+        for (int back = 1; back <= PRE; ++back) {
+            const int j = it - back;
+            if (j >= 0 && j % 3 == 0 && j / 3 + 1 < NCH) nP = true;
+        }
+        if (PRE == 2 && nW == 1) { if (nP) p3_wait<LW + LP>(); else p3_wait<LW>(); }
+        else { if (nP) p3_wait<LP>(); else p3_wait<0>(); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's patch ds_writes are done
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kw == 2 && chunk + 1 < NCH) store_patch((chunk + 1) & 1);
+        if (it + PRE < KI) issue_w(it + PRE);
+        asm volatile("" ::: "memory");
+        if (kw == 0 && chunk + 1 < NCH) load_patch(chunk + 1);
+
+        const char* pb = lds + (chunk & 1) * (TILES * P3_PATCH) + t * P3_PATCH;
+        const char* ws = wring + (it % NSTG) * P3_WSTAGE + (cg * 32) * 64 + wfrag;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int colb = ((r + kw + P3_TS * kh) & 15) * 16 + kh * 256;
+            bf16x8 wf[2], xf[P3_TP];
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+                wf[tc] = *reinterpret_cast<const bf16x8*>(ws + kh * 8192 + tc * 1024);
+#pragma unroll
+            for (int tp = 0; tp < P3_TP; ++tp)
+                xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
+#pragma unroll
+            for (int tp = 0; tp < P3_TP; ++tp)
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc)
+                    acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+        }
+        if (++kw == 3) { kw = 0; ++chunk; }
+    }
+
+    // ---- epilogue
+    const int cq = q * 4;
+    if (!a.dst_fp32 && (a.Cout & 7) == 0) {
+        constexpr int NSLOT = TILES * 176;
+        auto pix = [&](int slot) -> long long {
+            const int tt = slot / 176, p = slot - tt * 176;
+            const int g = tb * TILES + tt;
+            if (p >= P3_NPIX || g >= a.ntiles) return -1;
+            const int b = g / per_img, rem = g - b * per_img;
+            const int tyi = rem / a.tiles_x, txi = rem - tyi * a.tiles_x;
+            const int ty = p / P3_TS, tx = p - ty * P3_TS;
+            return ((long long)b * a.H + tyi * P3_TS + ty) * a.W + txi * P3_TS + tx;
+        };
+        __syncthreads();
+        if (a.res) {
+            tile_load_residual<NSLOT, 128, 256 * TILES>(lds, a.res, a.zero, a.Cout, n0, w, lane, pix);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int tp = 0; tp < P3_TP; ++tp) {
+            const int slot = t * 176 + tp * 16 + r;
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                const int chl = cg * 32 + tc * 16 + cq;
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + chl);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[tc][tp][e] + bs[e];
+                    if (a.leaky) x = x > 0.f ? x : 0.1f * x;
+                    v[e] = x;
+                }
+                tile_put<128>(lds, slot, chl, v, a.res != nullptr);
+            }
+        }
+        __syncthreads();
+        tile_store<NSLOT, 128, 256 * TILES>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
+        return;
+    }
+    if (!tvalid) return;
+#pragma unroll
+    for (int tp = 0; tp < P3_TP; ++tp) {
+        const int p = tp * 16 + r;
+        if (p >= P3_NPIX) continue;
+        const int ty = p / P3_TS, tx = p - ty * P3_TS;
+        const size_t m = ((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) {
+            const int ch = n0 + cg * 32 + tc * 16 + cq;
+            if (ch >= a.Cout) continue;
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + ch);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[tc][tp][e] + bs[e];
+                if (a.leaky) x = x > 0.f ? x : 0.1f * x;
+                v[e] = x;
+            }
+            const size_t o = m * a.Cout + ch;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ch + e >= a.Cout) break;
+                float x = v[e];
+                if (a.res) x += (float)a.res[o + e];
+                if (a.dst_fp32) ((float*)a.dst)[o + e] = x;
+                else ((__bf16*)a.dst)[o + e] = (__bf16)x;
             }
         }
     }
@@ -411,6 +788,24 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     YA_REQUIRE(d.cout_pad % BN == 0 && d.cout_pad >= d.cout, "conv: cout_pad=%d not a multiple of %d", d.cout_pad, BN);
     YA_REQUIRE((long long)d.B * d.H * d.W * (d.c0 + d.c1) < (1ll << 31) && (long long)d.cout_pad * K < (1ll << 31),
                "conv: tensor too large for 32-bit element offsets");
+    // stride-1 3x3 layers on 13*2^n feature maps: the patch-reuse kernel
+    if (d.ksize == 3 && d.stride == 1 && d.c1 == 0 && d.up0 == 0 && d.H % P3_TS == 0 && d.W % P3_TS == 0 &&
+        d.cout_pad % 128 == 0 && env_int("YOLO_AMD_CONV3", 0)) {
+        Conv3Args p;
+        p.src = (const __bf16*)d.src0; p.wgt = (const __bf16*)d.weight; p.bias = d.bias;
+        p.res = (const __bf16*)d.residual; p.dst = d.dst; p.zero = (const __bf16*)zero_page;
+        p.C = d.c0; p.H = d.H; p.W = d.W; p.Cout = d.cout; p.K = K; p.leaky = d.leaky; p.dst_fp32 = d.dst_fp32;
+        p.tiles_y = d.H / P3_TS; p.tiles_x = d.W / P3_TS; p.ntiles = d.B * p.tiles_y * p.tiles_x;
+        p.tiles_n = d.cout_pad / 128;
+        int tiles = env_int("YOLO_AMD_CONV3_TILES", 0);
+        if (tiles != 1 && tiles != 2) tiles = 1;
+        p.tiles_m = (p.ntiles + tiles - 1) / tiles;
+        if (tiles == 2)
+            hipLaunchKernelGGL(conv3x3_patch_kernel<2>, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, stream, p);
+        else
+            hipLaunchKernelGGL(conv3x3_patch_kernel<1>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        return YA_OK;
+    }
     ConvArgs a;
     a.src0 = (const __bf16*)d.src0; a.src1 = (const __bf16*)d.src1; a.wgt = (const __bf16*)d.weight;
     a.bias = d.bias; a.res = (const __bf16*)d.residual; a.dst = d.dst; a.zero = (const __bf16*)zero_page;
