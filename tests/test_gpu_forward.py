@@ -134,6 +134,7 @@ PATCH_CASES = [
 def test_conv3x3_patch_kernel(case, tiles, monkeypatch):
     from gpu_helpers import conv_reference, run_conv
     name, B, H, cin, cout, leaky, use_res, fp32_out = case
+    monkeypatch.setenv("YOLO_AMD_CONV3", "1")
     monkeypatch.setenv("YOLO_AMD_CONV3_TILES", str(tiles))
     r = gi.rs(abs(hash(name)) % 10000 + tiles)
     x0 = torch.from_numpy(r.standard_normal((B, H, H, cin)).astype(np.float32)).cuda().to(torch.bfloat16)

@@ -30,6 +30,8 @@ namespace yolo_amd {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct ConvArgs {
     const __bf16* src0;
@@ -667,59 +669,182 @@ conv3x3_patch_kernel(const Conv3Args a) {
 }
 
 // ---------------------------------------------------------------- first layer
-// Network input is NCHW fp32 with very few channels (3): K = 9*Cin is far too
-// short for an MFMA pipeline and the layer is bound by its 64-byte-per-pixel
-// output stream, so it is a direct convolution: one thread per output pixel,
-// weights (fp32 [k][cout], k = (kh*3 + kw)*Cin + c) broadcast from LDS.
+// Network input is NCHW fp32 with at most 3 channels, so K = 9*Cin <= 32 is a
+// single MFMA step: D[channel][pixel] = W[channel][k] * X[k][pixel] with
+// k = (kh*3 + kw)*Cin + c.  A workgroup takes 8x32-pixel tiles: it stages the
+// (8+2)x(32+2) input patch of every channel in LDS with range-checked buffer
+// loads (a coordinate outside the image gets an out-of-range offset and reads
+// as zero, so the padding is materialised once), then each wave handles four
+// strips of 16 consecutive pixels.  Lane (pixel n = lane & 15, k group
+// q = lane >> 4) gathers its eight im2col values from the patch, splits each
+// into a bf16 high part and a bf16 remainder (as are the weights, once, in
+// registers) and hi*hi + hi*lo + lo*hi accumulate on the otherwise idle matrix
+// pipe, which keeps the layer at fp32-level accuracy.  Weight rows are permuted
+// so that a lane's accumulators are eight consecutive channels of its own
+// pixel: one 16-byte store per lane, 1 KiB contiguous per wave.  The layer is
+// bound by its 64-byte-per-pixel output stream.
+constexpr uint32_t kRawBufferFlags = 0x00020000u;   // untyped 32-bit raw buffer descriptor word 3
+constexpr int FIRST_TH = 8, FIRST_TW = 32, FIRST_PH = FIRST_TH + 2, FIRST_PW = FIRST_TW + 2;
+
+// max(v, slope*v) for 0 < slope <= 1 as one median-of-three (no NaN
+// canonicalisation in front of it, unlike fmaxf)
+__device__ __forceinline__ float leaky_max(float v, float slope) {
+    return __builtin_amdgcn_fmed3f(v, slope * v, __builtin_inff());
+}
+
 template <int COUT>
 __global__ void __launch_bounds__(256)
 conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
-                  const float* __restrict__ bias, __bf16* __restrict__ dst, int Cin, int H, int W,
-                  int M, int leaky, FastDiv divHW, FastDiv divW) {
-    __shared__ __attribute__((aligned(16))) float sw[36 * COUT];
+                  const float* __restrict__ bias, __bf16* __restrict__ dst, int B, int Cin, int H, int W,
+                  float slope, uint32_t src_bytes, uint32_t dst_bytes, int tiles_x, int tiles_y) {
+    constexpr int NM = COUT / 16;
+    static_assert(NM == 1 || NM == 2, "first layer: 16 or 32 output channels");
+    constexpr int PH = FIRST_PH, PW = FIRST_PW, PLANE = PH * PW;
+    __shared__ float patch[3 * PLANE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
     const int K = 9 * Cin;
-    for (int i = threadIdx.x; i < K * COUT; i += 256) sw[i] = wgt[i];
-    __syncthreads();
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= M) return;
-    const uint32_t b = fdiv_u32((uint32_t)m, divHW);
-    const uint32_t rem = (uint32_t)m - b * (uint32_t)(H * W);
-    const int oy = (int)fdiv_u32(rem, divW);
-    const int ox = (int)rem - oy * W;
-    float acc[COUT];
+
+    // patch index of this lane's eight k values relative to the top-left corner
+    // of its pixel's window; k >= K (zero weight) re-reads the corner
+    int offl[8];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
-    const float* img = src + (size_t)b * Cin * H * W;
-    for (int kh = 0; kh < 3; ++kh) {
-        const int iy = oy + kh - 1;
-        for (int kw = 0; kw < 3; ++kw) {
-            const int ix = ox + kw - 1;
-            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            for (int c = 0; c < Cin; ++c) {
-                const float x = ok ? img[((size_t)c * H + iy) * W + ix] : 0.f;
-                const float* wk = sw + ((kh * 3 + kw) * Cin + c) * COUT;
-#pragma unroll
-                for (int co = 0; co < COUT; co += 4) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wk + co);
-                    acc[co + 0] += x * w4[0];
-                    acc[co + 1] += x * w4[1];
-                    acc[co + 2] += x * w4[2];
-                    acc[co + 3] += x * w4[3];
-                }
-            }
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j;
+        offl[j] = 0;
+        if (k < K) {
+            const int tap = k / Cin, c = k - tap * Cin;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            offl[j] = (c * PH + kh) * PW + kw;
         }
     }
-    __bf16* o = dst + (size_t)m * COUT;
+    // MFMA i, row r  <->  channel 8*(r>>2) + 4*i + (r&3)   (NM == 2)
+    bf16x8 wf[NM], wl[NM];
+    f32x4 bv[NM];
 #pragma unroll
-    for (int co = 0; co < COUT; co += 8) {
-        bf16x8 pk;
+    for (int i = 0; i < NM; ++i) {
+        const int ch = NM == 2 ? 8 * (n >> 2) + 4 * i + (n & 3) : n;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            float x = acc[co + r];
-            if (leaky) x = x > 0.f ? x : 0.1f * x;
-            pk[r] = (__bf16)x;
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * q + j;
+            const float wv = k < K ? wgt[k * COUT + ch] : 0.f;
+            wf[i][j] = (__bf16)wv;
+            wl[i][j] = (__bf16)(wv - (float)wf[i][j]);
         }
-        *reinterpret_cast<bf16x8*>(o + co) = pk;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[i][t] = bias[NM == 2 ? 8 * q + 4 * i + t : 4 * q + t];
+    }
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)src_bytes, (int)kRawBufferFlags);
+
+    const __amdgpu_buffer_rsrc_t rd =
+        __builtin_amdgcn_make_buffer_rsrc((void*)dst, 0, (int)dst_bytes, (int)kRawBufferFlags);
+
+    // The patch elements this thread stages (the same four for every tile):
+    // offset inside the image relative to the patch origin, and patch row/column.
+    const int per_image = tiles_x * tiles_y, ntiles = per_image * B;
+    const int total = Cin * PLANE;
+    int pre[4], prc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = min((int)threadIdx.x + 256 * u, total - 1);
+        const int c = e / PLANE, r2 = e - c * PLANE;
+        const int r = r2 / PW, col = r2 - r * PW;
+        pre[u] = (c * H + r) * W + col;
+        prc[u] = (r << 16) | col;
+    }
+    // Loads of a tile's patch into registers.  Every load and store of the loop
+    // below is issued unconditionally (out-of-range offsets instead of
+    // predication) so the number of memory operations in flight is static and
+    // the next tile's patch streams in while this tile is computed.
+    uint32_t stage[4];
+    auto fetch = [&](int tile, uint32_t (&st)[4]) {
+        const int b = tile / per_image, t2 = tile - b * per_image;
+        const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
+        const int x0 = tx * FIRST_TW - 1, y0 = ty * FIRST_TH - 1;
+        const int origin = (b * Cin * H + y0) * W + x0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gy = y0 + (prc[u] >> 16), gx = x0 + (prc[u] & 0xffff);
+            const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+            const uint32_t o = ok ? (uint32_t)((origin + pre[u]) * 4) : 0x80000000u;
+            st[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o, 0, 0);
+        }
+    };
+    auto dummy_stores = [&]() {
+        // Four range-dropped stores: they keep the sequence of outstanding
+        // memory operations at loop entry equal to the one the back edge
+        // carries, so the counted waits for a patch never include the stores
+        // of the tiles in between.
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if constexpr (NM == 2)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rd, (int)(0xFFFFFF00u + 16u * u), 0, 0);
+            else
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rd, (int)(0xFFFFFF00u + 16u * u), 0, 0);
+        }
+    };
+    if ((int)blockIdx.x >= ntiles) return;
+    const int step = gridDim.x, last = ntiles - 1;
+    fetch(blockIdx.x, stage);
+    dummy_stores();
+    for (int tile = blockIdx.x; tile < ntiles; tile += step) {
+        const int b = tile / per_image, t2 = tile - b * per_image;
+        const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
+        __syncthreads();                                   // previous tile's gathers are done
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if ((int)threadIdx.x + 256 * u < total) patch[threadIdx.x + 256 * u] = __uint_as_float(stage[u]);
+        __syncthreads();
+        fetch(min(tile + step, last), stage);              // next tile streams in meanwhile
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int row = 2 * wave + (sidx >> 1), colp = (sidx & 1) * 16 + n;
+            const float* pp = patch + row * PW + colp;
+            bf16x8 xf, xl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = pp[offl[j]];
+                xf[j] = (__bf16)t;
+                xl[j] = (__bf16)(t - (float)xf[j]);
+            }
+            f32x4 acc[NM];
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xf, bv[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xl, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf, acc[i], 0, 0, 0);
+            }
+            // The MFMA leaves lane (n, q) with chunk q of pixel n; a lane
+            // permutation (through the LDS crossbar, no memory) gives lane l
+            // chunk l & 3 of pixel l >> 2, so the wave's store is 1 KiB in lane
+            // order: whole 64-byte sectors per group of four lanes.
+            const int src_lane4 = (16 * (lane & 3) + (lane >> 2)) * 4;
+            const int y = ty * FIRST_TH + row, x = tx * FIRST_TW + (sidx & 1) * 16 + (lane >> 2);
+            const uint32_t pixel = (uint32_t)((b * H + y) * W + x);
+            const bool ok = y < H && x < W;
+            if constexpr (NM == 2) {
+                bf16x8 pk;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pk[4 * i + t] = (__bf16)leaky_max(acc[i][t], slope);
+                u32x4 w = __builtin_bit_cast(u32x4, pk);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) w[t] = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)w[t]);
+                const uint32_t o = ok ? pixel * (uint32_t)(COUT * 2) + 16u * (lane & 3) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_buffer_store_b128(w, rd, (int)o, 0, 0);
+            } else {
+                bf16x4 pk;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pk[t] = (__bf16)leaky_max(acc[0][t], slope);
+                u32x2 w = __builtin_bit_cast(u32x2, pk);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) w[t] = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)w[t]);
+                const uint32_t o = ok ? pixel * (uint32_t)(COUT * 2) + 8u * (lane & 3) : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_buffer_store_b64(w, rd, (int)o, 0, 0);
+            }
+        }
     }
 }
 
@@ -728,7 +853,8 @@ static int pick_bk(int c0, int c1) { return (c0 % 64 == 0 && c1 % 64 == 0) ? 64 
 static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
 
 template <int BM, int BN, int BK, int WAVES_M, int NSTAGE>
-static void launch_igemm(const ConvArgs& a, hipStream_t stream) {
+static void launch_igemm(ConvArgs a, hipStream_t stream) {
+    a.tiles_m = (a.M + BM - 1) / BM;
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, NSTAGE>), dim3(a.tiles_m * a.tiles_n),
                        dim3(256), 0, stream, a);
 }
@@ -752,23 +878,27 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     const long long M = (long long)d.B * Ho * Wo;
     YA_REQUIRE(M < (1ll << 31), "conv: too many output pixels");
     if (d.first_layer) {
-        YA_REQUIRE(d.ksize == 3 && d.stride == 1 && d.c0 >= 1 && d.c0 <= 4 && d.c1 == 0 && !d.residual &&
+        YA_REQUIRE(d.ksize == 3 && d.stride == 1 && d.c0 >= 1 && d.c0 <= 3 && d.c1 == 0 && !d.residual &&
                        !d.dst_fp32 && d.up0 == 0,
-                   "conv: first layer must be 3x3 stride 1 with at most 4 input channels");
-        FastDiv dHW = make_fastdiv((uint32_t)(d.H * d.W)), dW = make_fastdiv((uint32_t)d.W);
-        dim3 grid((unsigned)((M + 255) / 256));
-        if (d.cout == 32) {
-            hipLaunchKernelGGL(conv_first_kernel<32>, grid, dim3(256), 0, stream, (const float*)d.src0,
-                               (const float*)d.weight, d.bias, (__bf16*)d.dst, d.c0, d.H, d.W, (int)M,
-                               d.leaky, dHW, dW);
-        } else if (d.cout == 16) {
-            hipLaunchKernelGGL(conv_first_kernel<16>, grid, dim3(256), 0, stream, (const float*)d.src0,
-                               (const float*)d.weight, d.bias, (__bf16*)d.dst, d.c0, d.H, d.W, (int)M,
-                               d.leaky, dHW, dW);
-        } else {
+                   "conv: first layer must be 3x3 stride 1 with at most 3 input channels");
+        const long long src_bytes = (long long)d.B * d.c0 * d.H * d.W * 4, dst_bytes = M * d.cout * 2;
+        YA_REQUIRE(src_bytes < (1ll << 31) && dst_bytes < 0xFFFFFF00ll,
+                   "conv: first layer input must be smaller than 2 GiB and its output smaller than 4 GiB");
+        const int tiles_x = (d.W + FIRST_TW - 1) / FIRST_TW, tiles_y = (d.H + FIRST_TH - 1) / FIRST_TH;
+        const long long ntiles = (long long)tiles_x * tiles_y * d.B;
+        dim3 grid((unsigned)std::min<long long>(ntiles, 256 * 8 * 4));
+        const float slope = d.leaky ? 0.1f : 1.0f;
+#define YA_FIRST(CO)                                                                               \
+    hipLaunchKernelGGL((conv_first_kernel<CO>), grid, dim3(256), 0, stream, (const float*)d.src0, \
+                       (const float*)d.weight, d.bias, (__bf16*)d.dst, d.B, d.c0, d.H, d.W, slope, \
+                       (uint32_t)src_bytes, (uint32_t)dst_bytes, tiles_x, tiles_y)
+        if (d.cout == 32) YA_FIRST(32);
+        else if (d.cout == 16) YA_FIRST(16);
+        else {
             set_error("conv: first layer with %d output channels is not instantiated (16 or 32)", d.cout);
             return YA_ERR_UNSUPPORTED;
         }
+#undef YA_FIRST
         return YA_OK;
     }
     YA_REQUIRE(zero_page, "conv: zero page missing");
