@@ -102,8 +102,11 @@ int yolo_amd_filter_img_class(const float* rows8, int m, float cls, float nms_th
  * optional LeakyReLU(0.1) + optional residual add (the following shortcut
  * block) on an input that may be the channel concatenation of a nearest-2x
  * upsampled tensor and a second tensor (the route block in front of it).
- * Activations are NHWC bf16; weights are [cout_pad][K_pad] bf16 with
- * k = (kh*ksize + kw)*Cin + c, zero padded. */
+ * Activations are NHWC bf16.  Weights are bf16, zero padded to cout_pad
+ * output channels, stored K-tile major as [K/32][cout_pad][32] with
+ * k = (kh*ksize + kw)*Cin + c (Cin a multiple of 32): the 32-wide slice of
+ * reduction indices a workgroup stages for its channel tile is one contiguous
+ * run of whole cache lines. */
 typedef struct {
     const void* src0;     /* NHWC bf16, (B, H >> up0, W >> up0, c0); for the   */
                           /* first layer: NCHW fp32 (B, c0, H, W)               */
@@ -116,7 +119,7 @@ typedef struct {
     int B, H, W;          /* input spatial size seen by the convolution         */
     int cout, cout_pad;   /* real and padded output channels                    */
     int ksize, stride;    /* 1 or 3; 1 or 2 (padding = ksize / 2)               */
-    int k_pad;            /* padded reduction length = weight row stride        */
+    int k_pad;            /* reduction length K = ksize*ksize*(c0 + c1)         */
     int leaky;            /* apply LeakyReLU(0.1)                               */
     int dst_fp32;         /* 1: dst is fp32 (detection convs), 0: bf16          */
     int first_layer;      /* 1: src0 is the NCHW fp32 network input             */

@@ -72,8 +72,8 @@ def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     cout_pad = lib.yolo_amd_conv_cout_pad(cout)
     K = k * k * cin
-    wp = torch.zeros((cout_pad, K), dtype=torch.bfloat16, device=dev)
-    wp[:cout] = w.permute(0, 2, 3, 1).reshape(cout, K).to(dev).to(torch.bfloat16)
+    from yolo_amd.engine import pack_conv_weights
+    wp = pack_conv_weights(w.permute(0, 2, 3, 1).reshape(cout, K).to(dev), cout_pad)
     bp = torch.zeros(cout_pad, dtype=torch.float32, device=dev)
     bp[:cout] = bias.to(dev)
     out = torch.full((B, Ho, Wo, cout), float("nan"), dtype=torch.float32 if fp32_out else torch.bfloat16,

@@ -18,6 +18,7 @@ import torch
 
 from yolo_amd import _lib
 from yolo_amd._lib import ConvDesc, check, lib
+from yolo_amd.engine import pack_conv_weights
 
 # name, H(in), cin, cout, k, stride, residual
 LAYERS = [
@@ -51,7 +52,7 @@ def make_desc(B, H, cin, cout, k, stride, residual, dev):
     x = torch.randn((B, H, H, cin), generator=g).to(dev).to(torch.bfloat16)
     cout_pad = lib.yolo_amd_conv_cout_pad(cout)
     K = k * k * cin
-    w = (torch.randn((cout_pad, K), generator=g) * (2.0 / K) ** 0.5).to(dev).to(torch.bfloat16)
+    w = pack_conv_weights((torch.randn((cout_pad, K), generator=g) * (2.0 / K) ** 0.5).to(dev), cout_pad)
     bias = torch.randn(cout_pad, generator=g).to(dev)
     fp32 = cout == 255
     out = torch.empty((B, Ho, Ho, cout), dtype=torch.float32 if fp32 else torch.bfloat16, device=dev)
@@ -72,13 +73,13 @@ def make_desc(B, H, cin, cout, k, stride, residual, dev):
 
 def set_variant(v):
     for key in ("YOLO_AMD_CONV_NSTAGE", "YOLO_AMD_CONV_BK", "YOLO_AMD_CONV_TILE", "YOLO_AMD_CONV3",
-                "YOLO_AMD_CONV3_TILES"):
+                "YOLO_AMD_CONV3_TILES", "YOLO_AMD_CONV_AMUL"):
         os.environ.pop(key, None)
     for item in filter(None, v.split(",")):
         k, val = item.split("=")
         os.environ[{"ns": "YOLO_AMD_CONV_NSTAGE", "bk": "YOLO_AMD_CONV_BK",
                     "tile": "YOLO_AMD_CONV_TILE", "p3": "YOLO_AMD_CONV3",
-                    "p3t": "YOLO_AMD_CONV3_TILES"}[k]] = val
+                    "p3t": "YOLO_AMD_CONV3_TILES", "am": "YOLO_AMD_CONV_AMUL"}[k]] = val
 
 
 def main():

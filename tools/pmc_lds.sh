@@ -1,16 +1,14 @@
 #!/bin/bash
-# PMC passes (one rocprofv3 run per pass) over tools/conv_bench.py for the layers given in $1
-# and the kernel variant in $2; prints per-launch means of the counters for the conv kernels.
+# LDS-side PMC pass over tools/conv_bench.py for the layers in $1, variant $2.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-LAYERS="$1"; VAR="${2:-ns=2}"; TAG="${3:-pmc}"
+LAYERS="$1"; VAR="${2:-ns=2}"; TAG="${3:-pmcl}"
 mkdir -p gpurun_out/$TAG
 run() {
   name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/$TAG/$name -- python tools/conv_bench.py --reps 3 --layers "$LAYERS" --variants "$VAR" > gpurun_out/$TAG/$name.log 2>&1 || { echo "pass $name failed"; tail -5 gpurun_out/$TAG/$name.log; exit 1; }
 }
-run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS && \
-run tc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TOTAL_ACCESSES_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE && \
-run tc2 TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUSY_sum TCP_TCC_NC_READ_REQ_sum TCP_TCC_UC_READ_REQ_sum TCP_TCC_CC_READ_REQ_sum TCP_TCC_RW_READ_REQ_sum TA_TA_BUSY_sum TA_BUFFER_LOAD_WAVEFRONTS_sum
+run l1 SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL GRBM_GUI_ACTIVE && \
+run l2 SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
 python - "$TAG" <<'PY'
 import csv, glob, collections, sys
 for f in sorted(glob.glob(f"gpurun_out/{sys.argv[1]}/*/*/*counter_collection.csv")):

@@ -148,21 +148,29 @@ __device__ __forceinline__ void wait_stages(int stages) {
     }
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int NSTAGE>
+// AMUL = 2: the activation tile is two K-steps deep (BK*2 channels, a whole
+// 128-byte line per pixel when BK = 32) while the weight tile stays BK deep, so
+// every line the activation gather pulls from L2 is used completely and the
+// ring still fits three workgroups per CU.
+template <int BM, int BN, int BK, int WAVES_M, int NSTAGE, int AMUL = 1>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvArgs a) {
-    constexpr int CH = BK / 8;                 // 16-byte chunks per tile row
-    constexpr int RPI = 64 / CH;               // tile rows filled by one wave-instruction
+    constexpr int BKA = BK * AMUL;             // depth of the activation tile
+    constexpr int CH = BKA / 8;                // 16-byte chunks per activation tile row
+    constexpr int RPI = 64 / CH;               // activation tile rows filled by one wave-instruction
+    constexpr int CHW = BK / 8, RPIW = 64 / CHW;   // the same for the weight tile
     constexpr int WAVES_N = 4 / WAVES_M;
     constexpr int WMP = BM / WAVES_M;          // pixels per wave
     constexpr int WNC = BN / WAVES_N;          // channels per wave
     constexpr int TP = WMP / 16, TC = WNC / 16;
     constexpr int TA = BM * CH / 64;           // wave-instructions per activation tile
-    constexpr int TB = BN * CH / 64;           // ... per weight tile
+    constexpr int TB = BN * CHW / 64;          // ... per weight tile
     constexpr int NA = (TA + 3) / 4, NB = (TB + 3) / 4;   // per wave
-    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;
+    constexpr int A_BYTES = BM * BKA * 2, B_BYTES = BN * BK * 2;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int KSTEPS = BK / 32;
+    static_assert(AMUL == 1 || (AMUL == 2 && NSTAGE == 2 && BK == 32 && TA % 4 == 0),
+                  "the two-step activation tile is built for BK = 32 and a two-deep ring");
     constexpr int PRE = NSTAGE - 1;            // stages issued ahead of the one being computed
     // counted waits need every wave to issue the same number of loads per stage
     constexpr bool UNIFORM = (TA % 4 == 0) && (TB % 4 == 0);
@@ -195,6 +203,7 @@ conv_igemm_kernel(const ConvArgs a) {
     const int H0 = a.H >> a.up0, W0 = a.W >> a.up0;
 
     // ---- per-lane source bookkeeping for the LDS-DMA slots this lane fills
+    const int cout_pad = a.tiles_n * BN;
     int off0[NA], off1[NA], vmask[NA], woff[NB];
     int koff;                                   // element offset of this lane's chunk in a K-tile
     {
@@ -203,7 +212,7 @@ conv_igemm_kernel(const ConvArgs a) {
         for (int i = 0; i < NA; ++i) {
             const int j = i * 4 + w;
             const int row = j * RPI + lane / CH;
-            if (i == 0) koff = (cprime ^ chunk_swizzle<BK>(row)) * 8;   // same for every i (see conv_layout.h)
+            if (i == 0) koff = (cprime ^ chunk_swizzle<BKA>(row)) * 8;  // same for every i (see conv_layout.h)
             const int m = m0 + row;
             const bool vm = (j < TA) && (m < a.M);
             const int mm = vm ? m : 0;
@@ -233,8 +242,11 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int j = i * 4 + w;
-            const int row = j * RPI + lane / CH;
-            woff[i] = (n0 + row) * a.Kpad + koff;
+            const int row = j * RPIW + lane / CHW;
+            const int kw = ((lane % CHW) ^ chunk_swizzle<BK>(row)) * 8;
+            // weights are stored K-tile major, [K/32][cout_pad][32]: the rows of a
+            // workgroup's tile are one contiguous run of whole cache lines
+            woff[i] = ((kw >> 5) * cout_pad + n0 + row) * 32 + (kw & 31);
         }
     }
 
@@ -242,44 +254,60 @@ conv_igemm_kernel(const ConvArgs a) {
     int k_c = 0, k_tap = 0, k_kh = 0, k_kw = 0;
     const int pad = a.ksize >> 1;
 
-    auto stage = [&](int buf, int kt) {
-        char* sA = lds + buf * STAGE;
-        char* sB = sA + A_BYTES;
-        const bool second = k_c >= a.C0;
-        const __bf16* base = second ? a.src1 : a.src0;
-        const int Csrc = second ? a.C1 : a.C0;
-        const int Wsrc = second ? a.W : W0;
-        const int delta = ((k_kh - pad) * Wsrc + (k_kw - pad)) * Csrc + (second ? k_c - a.C0 : k_c) + koff;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int j = i * 4 + w;
-            if ((TA % 4 == 0) || j < TA) {
-                const bool v = (vmask[i] >> k_tap) & 1;
-                const int eo = (second ? off1[i] : off0[i]) + delta;
-                const __bf16* p = v ? (base + eo) : a.zero;
-                lds_dma16(p, sA + j * 1024);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int j = i * 4 + w;
-            if ((TB % 4 == 0) || j < TB) lds_dma16(a.wgt + (woff[i] + kt * BK), sB + j * 1024);
-        }
-        // advance the walker
-        k_c += BK;
+    // activation tile at the walker's position: uniform part, one LDS-DMA
+    // instruction of this wave's NA, and the walker's advance
+    const __bf16* act_base = nullptr;
+    int act_delta = 0, act_tap = 0;
+    bool act_second = false;
+    auto act_begin = [&]() {
+        act_second = k_c >= a.C0;
+        act_base = act_second ? a.src1 : a.src0;
+        const int Csrc = act_second ? a.C1 : a.C0;
+        const int Wsrc = act_second ? a.W : W0;
+        act_delta = ((k_kh - pad) * Wsrc + (k_kw - pad)) * Csrc + (act_second ? k_c - a.C0 : k_c) + koff;
+        act_tap = k_tap;
+        k_c += BKA;
         if (k_c >= Cin) {
             k_c = 0;
             ++k_tap;
             if (++k_kw == a.ksize) { k_kw = 0; ++k_kh; }
         }
     };
+    auto act_one = [&](char* sA, int i) {
+        const int j = i * 4 + w;
+        if ((TA % 4 == 0) || j < TA) {
+            const bool v = (vmask[i] >> act_tap) & 1;
+            const int eo = (act_second ? off1[i] : off0[i]) + act_delta;
+            const __bf16* p = v ? (act_base + eo) : a.zero;
+            lds_dma16(p, sA + j * 1024);
+        }
+    };
+    auto stage_act = [&](char* sA) {
+        act_begin();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) act_one(sA, i);
+    };
+    auto stage_wgt = [&](char* sB, int kt) {    // weight tile of K-step kt
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int j = i * 4 + w;
+            if ((TB % 4 == 0) || j < TB) lds_dma16(a.wgt + (woff[i] + kt * (BK * cout_pad)), sB + j * 1024);
+        }
+    };
+    auto stage = [&](int buf, int kt) {
+        char* sA = lds + buf * STAGE;
+        stage_act(sA);
+        stage_wgt(sA + A_BYTES, kt);
+    };
 
     // ---- fragment read offsets (bytes inside a tile), one per k-step
-    int frag_off[KSTEPS];
+    int frag_off[KSTEPS * AMUL], frag_off_w[KSTEPS];
     {
         const int r15 = lane & 15, q = lane >> 4;
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) frag_off[ks] = slot_of<BK>(r15, ks * 4 + q) * 16;
+        for (int ks = 0; ks < KSTEPS * AMUL; ++ks) frag_off[ks] = slot_of<BKA>(r15, ks * 4 + q) * 16;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) frag_off_w[ks] = slot_of<BK>(r15, ks * 4 + q) * 16;
     }
 
     f32x4 acc[TC][TP];
@@ -293,34 +321,82 @@ conv_igemm_kernel(const ConvArgs a) {
     // The wait is counted (never vmcnt(0) in the steady state) and the barrier
     // is a bare s_barrier: a __syncthreads() here would drain the DMA queue.
     const int KT = a.Kpad / BK;
+    // hook(tc) runs after the MFMAs of channel group tc: the place to issue
+    // loads one at a time between the matrix instructions
+    auto multiply = [&](const char* sA, const char* sB, int ks_a, int ks_w, auto&& hook) {
+        bf16x8 wf[TC], xf[TP];
 #pragma unroll
-    for (int s = 0; s < PRE; ++s)
-        if (s < KT) stage(s, s);
-    int cur = 0, nxt = PRE % NSTAGE;
-    for (int kt = 0; kt < KT; ++kt) {
-        wait_stages<PRE - 1, LPS>(min(PRE - 1, KT - 1 - kt));   // this wave's part of tile kt landed
-        __builtin_amdgcn_s_barrier();                          // everyone's did; tile kt-1 fully read
-        asm volatile("" ::: "memory");
-        if (kt + PRE < KT) stage(nxt, kt + PRE);
-        const char* sA = lds + cur * STAGE + (wm * WMP) * (BK * 2);
-        const char* sB = lds + cur * STAGE + A_BYTES + (wn * WNC) * (BK * 2);
+        for (int tc = 0; tc < TC; ++tc)
+            wf[tc] = *reinterpret_cast<const bf16x8*>(sB + tc * 16 * (BK * 2) + frag_off_w[ks_w]);
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            bf16x8 wf[TC], xf[TP];
+        for (int tp = 0; tp < TP; ++tp)
+            xf[tp] = *reinterpret_cast<const bf16x8*>(sA + tp * 16 * (BKA * 2) + frag_off[ks_a]);
 #pragma unroll
-            for (int tc = 0; tc < TC; ++tc)
-                wf[tc] = *reinterpret_cast<const bf16x8*>(sB + tc * 16 * (BK * 2) + frag_off[ks]);
+        for (int tc = 0; tc < TC; ++tc) {
 #pragma unroll
             for (int tp = 0; tp < TP; ++tp)
-                xf[tp] = *reinterpret_cast<const bf16x8*>(sA + tp * 16 * (BK * 2) + frag_off[ks]);
-#pragma unroll
-            for (int tc = 0; tc < TC; ++tc)
-#pragma unroll
-                for (int tp = 0; tp < TP; ++tp)
-                    acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+                acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+            hook(tc);
         }
-        cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
-        nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+    };
+    auto no_hook = [](int) {};
+    if constexpr (AMUL == 2) {
+        // LDS: two activation tiles (two K-steps each), then two weight tiles.
+        // Even step: needs its activation tile and weight tile; issues the next
+        // weight tile, then the next activation tile.  Odd step: needs only its
+        // weight tile, so the younger activation loads stay in flight across it.
+        char* const ldsW = lds + 2 * A_BYTES;
+        const int a_row = (wm * WMP) * (BKA * 2), w_row = (wn * WNC) * (BK * 2);
+        stage_act(lds);
+        stage_wgt(ldsW, 0);
+        static_assert(NA % TC == 0 || TC % NA == 0, "activation loads spread evenly over the MFMA groups");
+        for (int kt = 0; kt < KT; kt += 2) {
+            char* const sA = lds + ((kt >> 1) & 1) * A_BYTES;
+            char* const sAn = lds + (((kt >> 1) & 1) ^ 1) * A_BYTES;
+            const bool more = kt + 2 < KT;
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            stage_wgt(ldsW + B_BYTES, kt + 1);
+            if (more) act_begin();
+            multiply(sA + a_row, ldsW + w_row, 0, 0, [&](int tc) {
+                // the next activation tile goes out a load at a time between the
+                // MFMA groups: a burst right after the barrier would queue every
+                // wave of the CU on the one address unit
+                if (more) {
+                    if constexpr (NA >= TC) {
+#pragma unroll
+                        for (int i = 0; i < NA / TC; ++i) act_one(sAn, tc * (NA / TC) + i);
+                    } else {
+                        if (tc % (TC / NA) == 0) act_one(sAn, tc / (TC / NA));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (more) wait_vmcnt<NA>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (more) stage_wgt(ldsW, kt + 2);
+            multiply(sA + a_row, ldsW + B_BYTES + w_row, 1, 0, no_hook);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < PRE; ++s)
+            if (s < KT) stage(s, s);
+        int cur = 0, nxt = PRE % NSTAGE;
+        for (int kt = 0; kt < KT; ++kt) {
+            wait_stages<PRE - 1, LPS>(min(PRE - 1, KT - 1 - kt));   // this wave's part of tile kt landed
+            __builtin_amdgcn_s_barrier();                          // everyone's did; tile kt-1 fully read
+            asm volatile("" ::: "memory");
+            if (kt + PRE < KT) stage(nxt, kt + PRE);
+            const char* sA = lds + cur * STAGE + (wm * WMP) * (BK * 2);
+            const char* sB = lds + cur * STAGE + A_BYTES + (wn * WNC) * (BK * 2);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ++ks) multiply(sA, sB, ks, ks, no_hook);
+            cur = (cur + 1 == NSTAGE) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NSTAGE) ? 0 : nxt + 1;
+        }
     }
 
     // ---- epilogue: bias, LeakyReLU, residual, store
@@ -510,6 +586,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
         pdst[i] = (tf < TILES ? tf : 0) * P3_PATCH + fq * P3_PLANE + (py * 16 + ((fpx + P3_TS * py) & 15)) * 16;
     }
     // ---- weight fill: LW LDS-DMA instructions per wave per (chunk, kw) stage
+    const int cout_pad = a.tiles_n * 128;
     int woff[LW];
     {
         const int qw = (lane & 3) ^ chunk_swizzle<32>(lane >> 2);
@@ -517,12 +594,12 @@ conv3x3_patch_kernel(const Conv3Args a) {
         for (int i = 0; i < LW; ++i) {
             const int j = w + i * NW;          // 0..23: kh = j / 8, 16 channel rows each
             const int kh = j >> 3, n = (j & 7) * 16 + (lane >> 2);
-            woff[i] = (n0 + n) * a.K + kh * 3 * a.C + qw * 8;
+            woff[i] = ((kh * 3 * a.C / 32) * cout_pad + n0 + n) * 32 + qw * 8;   // [K/32][cout_pad][32]
         }
     }
     auto issue_w = [&](int it) {               // stage `it` = (chunk it/3, kw it%3)
         const int chunk = it / 3, kw = it - chunk * 3;
-        const int delta = kw * a.C + chunk * 32;
+        const int delta = (kw * a.C + chunk * 32) * cout_pad;
         char* dst = wring + (it % NSTG) * P3_WSTAGE;
 #pragma unroll
         for (int i = 0; i < LW; ++i) lds_dma16(a.wgt + (woff[i] + delta), dst + (w + i * NW) * 1024);
@@ -852,10 +929,10 @@ conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
 static int pick_bk(int c0, int c1) { return (c0 % 64 == 0 && c1 % 64 == 0) ? 64 : 32; }
 static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
 
-template <int BM, int BN, int BK, int WAVES_M, int NSTAGE>
+template <int BM, int BN, int BK, int WAVES_M, int NSTAGE, int AMUL = 1>
 static void launch_igemm(ConvArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, NSTAGE>), dim3(a.tiles_m * a.tiles_n),
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, NSTAGE, AMUL>), dim3(a.tiles_m * a.tiles_n),
                        dim3(256), 0, stream, a);
 }
 
@@ -951,19 +1028,29 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     // with three or four resident workgroups per CU beats deeper rings at one
     // workgroup per CU on every layer shape of the network.
     const int ns = env_int("YOLO_AMD_CONV_NSTAGE", 2);
+    // two-step activation tile (whole 128-byte lines per pixel): needs both
+    // sources in whole 64-channel groups; not worth it for the shortest K loops
+    const int amul = env_int("YOLO_AMD_CONV_AMUL", K >= 256 ? 2 : 1);
+    if (amul == 2 && BK == 32 && ns == 2 && d.c0 % 64 == 0 && d.c1 % 64 == 0) {
+        if (BN == 128) launch_igemm<128, 128, 32, 2, 2, 2>(a, stream);
+        else if (BN == 64) launch_igemm<128, 64, 32, 2, 2, 2>(a, stream);
+        else launch_igemm<128, 32, 32, 4, 2, 2>(a, stream);
+        return YA_OK;
+    }
     if (BN == 128 && BK == 64) {
         if (ns == 3) launch_igemm<128, 128, 64, 2, 3>(a, stream);
         else if (ns == 4) launch_igemm<128, 128, 64, 2, 4>(a, stream);
         else launch_igemm<128, 128, 64, 2, 2>(a, stream);
     } else if (BN == 128 && BK == 32) {
-        if (ns == 4) launch_igemm<128, 128, 32, 2, 4>(a, stream);
-        else if (ns == 5) launch_igemm<128, 128, 32, 2, 5>(a, stream);
+        if (ns == 3) launch_igemm<128, 128, 32, 2, 3>(a, stream);
+        else if (ns == 4) launch_igemm<128, 128, 32, 2, 4>(a, stream);
         else launch_igemm<128, 128, 32, 2, 2>(a, stream);
     } else if (BN == 64 && BK == 64) {
         if (ns == 4) launch_igemm<128, 64, 64, 2, 4>(a, stream);
         else launch_igemm<128, 64, 64, 2, 2>(a, stream);
     } else if (BN == 64 && BK == 32) {
-        if (ns == 4) launch_igemm<128, 64, 32, 2, 4>(a, stream);
+        if (ns == 3) launch_igemm<128, 64, 32, 2, 3>(a, stream);
+        else if (ns == 4) launch_igemm<128, 64, 32, 2, 4>(a, stream);
         else launch_igemm<128, 64, 32, 2, 2>(a, stream);
     } else if (BN == 32 && BK == 64) {
         if (ns == 4) launch_igemm<128, 32, 64, 4, 4>(a, stream);

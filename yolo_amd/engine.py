@@ -2,7 +2,7 @@
 
 Turns the cfg blocks + the model's parameters into what the HIP library runs:
 
-  * BatchNorm folded into bf16 weights [cout_pad][kh][kw][cin] and an fp32 bias
+  * BatchNorm folded into bf16 weights (K-tile major, see pack_conv_weights) and an fp32 bias
     (recomputed whenever weights are reloaded);
   * one ``yolo_amd_conv_desc`` per convolution, with the following shortcut
     block folded in as a residual operand and the preceding upsample / route
@@ -170,6 +170,17 @@ def build_ops(table, B, H, channels):
     return ops, heads, buf_info
 
 
+def pack_conv_weights(wk, cout_pad):
+    """[cout][K] weights (k = (kh*ks + kw)*cin + c, K a multiple of 32) -> the bf16
+    K-tile-major image [K/32][cout_pad][32] the conv kernels stage from, zero rows
+    for the padded output channels."""
+    cout, K = wk.shape
+    assert K % 32 == 0 and cout_pad >= cout
+    wp = torch.zeros((cout_pad, K), dtype=torch.bfloat16, device=wk.device)
+    wp[:cout] = wk.to(torch.bfloat16)
+    return wp.view(cout_pad, K // 32, 32).permute(1, 0, 2).contiguous()
+
+
 def place_buffers(buf_info):
     """First-fit placement by liveness, 256-byte aligned.  Returns
     ({buffer id: offset}, arena bytes)."""
@@ -305,8 +316,7 @@ class Plan:
                 wp = wk.t().contiguous()                           # fp32 [k][cout]
                 bp = bias.contiguous()
             else:
-                wp = torch.zeros((d.cout_pad, d.k_pad), dtype=torch.bfloat16, device=w.device)
-                wp[:cout, :wk.shape[1]] = wk.to(torch.bfloat16)
+                wp = pack_conv_weights(wk, d.cout_pad)
                 bp = torch.zeros(d.cout_pad, dtype=torch.float32, device=w.device)
                 bp[:cout] = bias
             self._packed.append((wp, bp))
