@@ -9,12 +9,14 @@
 //              (class asc, objectness desc, original row asc) and segment
 //              boundaries per (image, class)
 //   mask     : 64x64 tiles of the per-segment suppression matrix, one wave per
-//              tile, spread over the whole GPU: bit j of word (i, w) says box
-//              64w+j (later in the visiting order) is suppressed by box i
-//              (IoU in the reference's fp32 operation order)
+//              tile, spread over the whole GPU, stored tile by tile: bit j of
+//              word i of tile (t, w) says box 64w+j (later in the visiting
+//              order) is suppressed by box 64t+i (IoU in the reference's fp32
+//              operation order)
 //   reduce   : one workgroup per (image, class) segment walks the boxes in
-//              order, 64 at a time: resolves the diagonal word serially, then
-//              ORs the rows of the survivors into the "removed" bit vector
+//              order, 64 at a time: resolves the diagonal tile (serial only
+//              over boxes that suppress something), then ORs the survivors'
+//              words of the later tiles into the "removed" bit vector
 //   scan     : exclusive scan of kept counts -> output row offsets, total K
 //   gather   : write the (K, 9) rows
 //
@@ -207,7 +209,7 @@ nms_sort_kernel(const int* __restrict__ cand_count, int key_stride, int C,
         if (i == cnt - 1 || key_cls(sorted[i + 1]) != c) seg_end[b * C + c] = i + 1;
     }
     // Plan the suppression-matrix tiles: a segment of n boxes has T = ceil(n/64)
-    // word columns, T(T+1)/2 upper-triangular tiles and n*T mask words.
+    // word columns and T(T+1)/2 upper-triangular tiles of 64 mask words each.
     // Exclusive prefix sums over the classes give every segment its first tile
     // number and its mask offset.  (skeys is free now and serves as scratch.)
     __syncthreads();
@@ -221,7 +223,7 @@ nms_sort_kernel(const int* __restrict__ cand_count, int key_stride, int C,
             const int n = seg_end[b * C + c] - seg_start[b * C + c];
             const int T = (n + 63) >> 6;
             tiles = T * (T + 1) / 2;
-            words = n * T;
+            words = tiles * 64;
         }
         sa[threadIdx.x] = tiles;
         sb[threadIdx.x] = words;
@@ -251,8 +253,9 @@ nms_sort_kernel(const int* __restrict__ cand_count, int key_stride, int C,
 // Bit jj of the word: box j = 64*tj + jj comes later than i in the visiting
 // order and `iou(i, j) < thresh` is false (so iou >= thresh or NaN), which is
 // when the reference zeroes row j while box i is the pivot (utilis.py:379-381).
-// Off-diagonal words land in mask[i][tj] (row-major, T words per row), the
-// diagonal words in their own contiguous array.
+// The matrix is stored tile by tile (tile (ti, tj) of a segment at number
+// ti*T - ti*(ti-1)/2 + tj - ti, 64 words each, lane order), so a wave writes
+// and later reads a whole tile as one contiguous 512-byte run.
 constexpr int MASK_GRID_X = 256;
 
 __global__ void __launch_bounds__(256)
@@ -260,8 +263,7 @@ nms_mask_kernel(const unsigned long long* __restrict__ keys, int key_stride, int
                 const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                 const int* __restrict__ tile_base, const int* __restrict__ mask_off,
                 const int* __restrict__ total_tiles, const float4* __restrict__ boxes, int box_stride,
-                float thresh, unsigned long long* __restrict__ mask, size_t mask_stride,
-                unsigned long long* __restrict__ diag) {
+                float thresh, unsigned long long* __restrict__ mask, size_t mask_stride) {
     __shared__ float4 colbox[4][64];
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -279,7 +281,8 @@ nms_mask_kernel(const unsigned long long* __restrict__ keys, int key_stride, int
         const int s = seg_start[b * C + c];
         const int n = seg_end[b * C + c] - s;
         const int T = (n + 63) >> 6;
-        int rem = q - tile_base[b * C + c], ti = 0;
+        const int q_local = q - tile_base[b * C + c];
+        int rem = q_local, ti = 0;
         while (rem >= T - ti) { rem -= T - ti; ++ti; }
         const int tj = ti + rem;
         const int i = ti * 64 + lane, j0 = tj * 64;
@@ -299,28 +302,35 @@ nms_mask_kernel(const unsigned long long* __restrict__ keys, int key_stride, int
             if (ti == tj) sup = sup && (jj > lane);
             word |= (unsigned long long)sup << jj;
         }
-        if (i < n) {
-            if (ti == tj) diag[(size_t)b * N + s + i] = word;
-            else mask[(size_t)b * mask_stride + mask_off[b * C + c] + (size_t)i * T + tj] = word;
-        }
+        if (i >= n) word = 0;
+        mask[(size_t)b * mask_stride + mask_off[b * C + c] + (size_t)q_local * 64 + lane] = word;
     }
 }
 
 // ---------------------------------------------------------------- reduce
 // One workgroup (4 waves) per (image, class).  `removed` holds one bit per box
-// of the segment.  For each group of 64 boxes in visiting order, wave 0
-// resolves the group serially with the diagonal words (a box survives iff its
-// bit is still clear, and then sets the bits of the boxes it suppresses inside
-// the group); then all waves OR the mask rows of the survivors into the words
-// of the later groups.  A box survives iff `iou < thresh` held against every
-// earlier survivor: the reference's greedy loop (utilis.py:367-385).
+// of the segment.  For each group g of 64 boxes in visiting order, wave 0
+// resolves the group with its diagonal tile: a box survives iff its bit is
+// still clear, and then sets the bits of the boxes it suppresses inside the
+// group.  Only boxes that suppress something take a serial step (a box with an
+// empty word changes nothing), so a group without overlaps costs no loop at
+// all.  Then wave w takes the later groups' words w, w+4, ...: lane = box of
+// group g reads its word of tile (g, word), the survivors' words are OR-ed
+// across the wave and the result is merged into `removed`.  A box survives iff
+// `iou < thresh` held against every earlier survivor: the reference's greedy
+// loop (utilis.py:367-385).
 constexpr int REDUCE_MAX_WORDS = 512;    // 32768 boxes per segment
+
+__device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m, 64);
+    return v;
+}
 
 __global__ void __launch_bounds__(256)
 nms_reduce_kernel(int N, int C, const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                   const int* __restrict__ mask_off, const unsigned long long* __restrict__ mask,
-                  size_t mask_stride, const unsigned long long* __restrict__ diag,
-                  int* __restrict__ kept_pos, int* __restrict__ seg_kept) {
+                  size_t mask_stride, int* __restrict__ kept_pos, int* __restrict__ seg_kept) {
     __shared__ unsigned long long removed[REDUCE_MAX_WORDS];
     __shared__ unsigned long long kbits;
     const int c = blockIdx.x, b = blockIdx.y;
@@ -332,48 +342,40 @@ nms_reduce_kernel(int N, int C, const int* __restrict__ seg_start, const int* __
         return;
     }
     const int T = (n + 63) >> 6;
-    const unsigned long long* rows = mask + (size_t)b * mask_stride + mask_off[b * C + c];
-    const unsigned long long* dg = diag + (size_t)b * N + s;
+    const unsigned long long* tiles = mask + (size_t)b * mask_stride + mask_off[b * C + c];
+    auto tile = [&](int ti, int tj) { return tiles + (size_t)(ti * T - ti * (ti - 1) / 2 + tj - ti) * 64; };
     int* kp = kept_pos + (size_t)b * N + s;
     for (int w = threadIdx.x; w < T; w += 256) removed[w] = 0;
     __syncthreads();
     int nk = 0;
-    unsigned long long d_next = (wave == 0 && lane < n) ? dg[lane] : 0;
+    unsigned long long d_next = wave == 0 ? tile(0, 0)[lane] : 0;
     for (int g = 0; g < T; ++g) {
         if (wave == 0) {
             const unsigned long long d = d_next;
-            const int nidx = (g + 1) * 64 + lane;
-            d_next = (g + 1 < T && nidx < n) ? dg[nidx] : 0;          // prefetch the next group
+            if (g + 1 < T) d_next = tile(g + 1, g + 1)[lane];         // prefetch the next diagonal tile
             const int left = n - g * 64;
             const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-            unsigned long long cur = removed[g] | ~valid;
-            unsigned long long keep = 0;
-            while (~cur) {
-                const int i = __ffsll((long long)~cur) - 1;
-                const unsigned int dlo = __builtin_amdgcn_readlane((unsigned int)d, i);
-                const unsigned int dhi = __builtin_amdgcn_readlane((unsigned int)(d >> 32), i);
-                keep |= 1ull << i;
-                cur |= (1ull << i) | ((unsigned long long)dhi << 32) | dlo;
+            unsigned long long rem = removed[g] | ~valid;
+            unsigned long long act = __ballot(d != 0ull) & ~rem;
+            while (act) {
+                const int i = __ffsll((long long)act) - 1;
+                act &= act - 1ull;
+                if (!((rem >> i) & 1ull)) {
+                    const unsigned int dlo = __builtin_amdgcn_readlane((unsigned int)d, i);
+                    const unsigned int dhi = __builtin_amdgcn_readlane((unsigned int)(d >> 32), i);
+                    rem |= ((unsigned long long)dhi << 32) | dlo;
+                }
             }
+            const unsigned long long keep = ~rem;
             if ((keep >> lane) & 1ull) kp[nk + __popcll(keep & ((1ull << lane) - 1ull))] = g * 64 + lane;
             if (lane == 0) kbits = keep;
         }
         __syncthreads();
         const unsigned long long keep = kbits;
-        const int nwords = T - g - 1;
-        if (nwords > 0) {
-            // wave w takes the survivors number w, w+4, ... of this group
-            unsigned long long m = keep;
-            for (int k = 0; k < wave && m; ++k) m &= m - 1;
-            while (m) {
-                const int i = __ffsll((long long)m) - 1;
-                const unsigned long long* row = rows + (size_t)(g * 64 + i) * T + (g + 1);
-                for (int w = lane; w < nwords; w += 64) {
-                    const unsigned long long v = row[w];
-                    if (v) atomicOr(&removed[g + 1 + w], v);
-                }
-                for (int k = 0; k < 4 && m; ++k) m &= m - 1;
-            }
+        const bool mine = (keep >> lane) & 1ull;
+        for (int w = g + 1 + wave; w < T; w += 4) {
+            const unsigned long long v = wave_or(mine ? tile(g, w)[lane] : 0ull);
+            if (lane == 0 && v) removed[w] |= v;
         }
         nk += __popcll(keep);
         __syncthreads();
@@ -490,8 +492,7 @@ struct NmsWorkspace {
     int* tile_base;      // [B*C] first tile number of each segment
     int* mask_off;       // [B*C] first mask word of each segment (inside the image's region)
     int* total_tiles;    // [B]
-    unsigned long long* diag;   // [B][N] diagonal words of the suppression matrices
-    unsigned long long* mask;   // [B][mask_stride] off-diagonal words, row-major per segment
+    unsigned long long* mask;   // [B][mask_stride] suppression matrices, tile by tile per segment
     size_t mask_stride;
     int key_stride;
     size_t bytes;
@@ -519,9 +520,9 @@ static NmsWorkspace carve(void* base, int B, int N, int C) {
     w.tile_base = (int*)take(sizeof(int) * S);
     w.mask_off = (int*)take(sizeof(int) * S);
     w.total_tiles = (int*)take(sizeof(int) * (size_t)B);
-    w.diag = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)B * N);
-    // sum over segments of n * ceil(n/64) <= N*N/64 + N words per image
-    w.mask_stride = ((size_t)N * N + 63) / 64 + (size_t)N;
+    // per image: sum over segments of 32*T*(T+1) words, T = ceil(n/64), sum of n <= N
+    //   <= N*N/128 + 1.5*N + 64*min(N, C)
+    w.mask_stride = ((size_t)N * N + 127) / 128 + 2 * (size_t)N + 64 * (size_t)(N < C ? N : C);
     w.mask = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)B * w.mask_stride);
     w.bytes = off;
     return w;
@@ -573,9 +574,9 @@ extern "C" int yolo_amd_filter_results(const float* pred, int B, int N, int D, i
                        w.total_tiles);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, B), dim3(256), 0, stream, w.keys, w.key_stride,
                        N, C, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles, w.boxes, 1,
-                       nms_thresh, w.mask, w.mask_stride, w.diag);
+                       nms_thresh, w.mask, w.mask_stride);
     hipLaunchKernelGGL(nms_reduce_kernel, dim3(C, B), dim3(256), 0, stream, N, C, w.seg_start, w.seg_end,
-                       w.mask_off, w.mask, w.mask_stride, w.diag, w.kept_pos, w.seg_kept);
+                       w.mask_off, w.mask, w.mask_stride, w.kept_pos, w.seg_kept);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, B * C, w.seg_off,
                        out_count);
     hipLaunchKernelGGL(nms_gather_kernel, dim3(C, B), dim3(64), 0, stream, w.keys, w.key_stride, N, C,
@@ -612,9 +613,9 @@ extern "C" int yolo_amd_filter_img_class(const float* rows8, int m, float cls, f
                        w.total_tiles);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, 1), dim3(256), 0, stream, w.keys, w.key_stride,
                        m, 1, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles,
-                       reinterpret_cast<const float4*>(rows8), 2, nms_thresh, w.mask, w.mask_stride, w.diag);
+                       reinterpret_cast<const float4*>(rows8), 2, nms_thresh, w.mask, w.mask_stride);
     hipLaunchKernelGGL(nms_reduce_kernel, dim3(1, 1), dim3(256), 0, stream, m, 1, w.seg_start, w.seg_end,
-                       w.mask_off, w.mask, w.mask_stride, w.diag, w.kept_pos, w.seg_kept);
+                       w.mask_off, w.mask, w.mask_stride, w.kept_pos, w.seg_kept);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, 1, w.seg_off,
                        out_count);
     hipLaunchKernelGGL(rows8_gather_kernel, dim3(min(256, (m + 63) / 64)), dim3(64), 0, stream, w.keys,
