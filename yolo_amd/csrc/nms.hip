@@ -51,6 +51,38 @@ __device__ __forceinline__ float iou_ref(float4 p, float4 q) {
     return __fdiv_rn(inter, uni);
 }
 
+// The suppression matrix needs one IoU per pair of boxes of a segment, and the
+// NaN-propagating max/min/clamp above cost four instructions each.  For "tame"
+// boxes (every coordinate finite and below 1e18 in magnitude) no intermediate
+// can overflow or turn NaN before the division, so the plain v_max/v_min give
+// the same bits as tmax/tmin; the arithmetic and its order are unchanged.
+__device__ __forceinline__ bool box_tame(float4 p) {
+    const float L = 1e18f;
+    return fabsf(p.x) < L && fabsf(p.y) < L && fabsf(p.z) < L && fabsf(p.w) < L;
+}
+__device__ __forceinline__ float box_area(float4 p) {
+    return __fmul_rn(__fadd_rn(__fsub_rn(p.z, p.x), 1.0f), __fadd_rn(__fsub_rn(p.w, p.y), 1.0f));
+}
+// single instructions, without the NaN canonicalisation fmaxf/fminf put in front
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float iou_tame(float4 p, float a1, float4 q, float a2) {
+    const float ix1 = vmax(p.x, q.x), iy1 = vmax(p.y, q.y);
+    const float ix2 = vmin(p.z, q.z), iy2 = vmin(p.w, q.w);
+    const float iw = vmax(__fadd_rn(__fsub_rn(ix2, ix1), 1.0f), 0.0f);
+    const float ih = vmax(__fadd_rn(__fsub_rn(iy2, iy1), 1.0f), 0.0f);
+    const float inter = __fmul_rn(iw, ih);
+    return __fdiv_rn(inter, __fsub_rn(__fadd_rn(a1, a2), inter));
+}
+
 // ---------------------------------------------------------------- box_iou
 __global__ void __launch_bounds__(256)
 box_iou_kernel(const float* __restrict__ b1, int n1, const float* __restrict__ b2, int m,
@@ -265,6 +297,7 @@ nms_mask_kernel(const unsigned long long* __restrict__ keys, int key_stride, int
                 const int* __restrict__ total_tiles, const float4* __restrict__ boxes, int box_stride,
                 float thresh, unsigned long long* __restrict__ mask, size_t mask_stride) {
     __shared__ float4 colbox[4][64];
+    __shared__ float colarea[4][64];
     const int b = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nt = total_tiles[b];
@@ -296,12 +329,22 @@ nms_mask_kernel(const unsigned long long* __restrict__ keys, int key_stride, int
         __builtin_amdgcn_wave_barrier();
         const int ncol = min(64, n - j0);
         unsigned long long word = 0;
-        for (int jj = 0; jj < ncol; ++jj) {
-            const float4 cb = colbox[wave][jj];
-            bool sup = !(iou_ref(mine, cb) < thresh);
-            if (ti == tj) sup = sup && (jj > lane);
-            word |= (unsigned long long)sup << jj;
+        if (__ballot(!box_tame(mine) || !box_tame(col)) == 0ull) {
+            colarea[wave][lane] = box_area(col);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const float my_area = box_area(mine);
+            for (int jj = 0; jj < ncol; ++jj) {
+                const bool sup = !(iou_tame(mine, my_area, colbox[wave][jj], colarea[wave][jj]) < thresh);
+                word |= (unsigned long long)sup << jj;
+            }
+        } else {
+            for (int jj = 0; jj < ncol; ++jj) {
+                const bool sup = !(iou_ref(mine, colbox[wave][jj]) < thresh);
+                word |= (unsigned long long)sup << jj;
+            }
         }
+        if (ti == tj) word &= ~0ull << lane << 1;            // only boxes later in the order
         if (i >= n) word = 0;
         mask[(size_t)b * mask_stride + mask_off[b * C + c] + (size_t)q_local * 64 + lane] = word;
     }
