@@ -118,33 +118,51 @@ __device__ __forceinline__ float key_obj(unsigned long long k) {
 
 // ---------------------------------------------------------------- compact
 // Block = WAVES waves; each wave owns a tile of 64 consecutive rows of one
-// image and stages its 64*D floats through its own LDS slice with fully
-// coalesced loads (16 B per lane when the tile base allows it, else 4 B).
+// image and copies its 64*D floats into its own LDS slice by LDS-DMA: every
+// 16-byte piece of the tile is in flight at once and no register is used.
+// Rows are only 4-byte aligned (D = 85), so the copy starts at the 16-byte
+// boundary at or below the tile and the slice keeps the same misalignment.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// The per-image candidate counters take one atomic per wave; each sits in its
+// own 128-byte line so that the images' atomics do not queue on one L2 line.
+constexpr int CNT_STRIDE = 32;
+
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 nms_compact_kernel(const float* __restrict__ pred, int N, int D, int C, float conf,
-                   int key_stride, int* __restrict__ cand_count,
+                   int key_stride, int slice_bytes, int* __restrict__ cand_count,
                    unsigned long long* __restrict__ keys, float4* __restrict__ boxes,
                    float* __restrict__ scores) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int b = blockIdx.y;
     const int row0 = (blockIdx.x * WAVES + wave) * 64;
-    float* tile = lds + (size_t)wave * 64 * D;
+    char* slice = lds + (size_t)wave * slice_bytes;
     const int rows = min(64, N - row0);            // may be <= 0 for the tail wave
+    int mis = 0;
     if (rows > 0) {
-        const float* src = pred + ((size_t)b * N + row0) * D;
-        const int nfl = rows * D;
-        if (((uintptr_t)src & 15) == 0) {
-            const int n4 = nfl >> 2;
-            const float4* s4 = reinterpret_cast<const float4*>(src);
-            float4* t4 = reinterpret_cast<float4*>(tile);
-            for (int i = lane; i < n4; i += 64) t4[i] = s4[i];
-            for (int i = (n4 << 2) + lane; i < nfl; i += 64) tile[i] = src[i];
+        const char* src = reinterpret_cast<const char*>(pred + ((size_t)b * N + row0) * D);
+        const int nbytes = rows * D * 4;
+        mis = (int)((uintptr_t)src & 15);
+        const char* g0 = src - mis;
+        if (g0 < reinterpret_cast<const char*>(pred)) {
+            // first tile of a tensor that does not start on a 16-byte boundary
+            for (int i = lane * 4; i < nbytes; i += 256)
+                *reinterpret_cast<float*>(slice + mis + i) = *reinterpret_cast<const float*>(src + i);
         } else {
-            for (int i = lane; i < nfl; i += 64) tile[i] = src[i];
+            const int total = mis + nbytes, full = total >> 4;
+            for (int kb = 0; kb < full; kb += 64)
+                if (kb + lane < full) lds_dma16(g0 + (size_t)(kb + lane) * 16, slice + kb * 16);
+            for (int i = (full << 4) + lane * 4; i < total; i += 256)
+                *reinterpret_cast<float*>(slice + i) = *reinterpret_cast<const float*>(g0 + i);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    const float* tile = reinterpret_cast<const float*>(slice + mis);
     __syncthreads();
     bool pass = false;
     float obj = 0.f;
@@ -156,12 +174,13 @@ nms_compact_kernel(const float* __restrict__ pred, int N, int D, int C, float co
     unsigned long long m = __ballot(pass);
     if (m == 0) return;
     int base = 0;
-    if (lane == 0) base = atomicAdd(&cand_count[b], __popcll(m));
+    if (lane == 0) base = atomicAdd(&cand_count[b * CNT_STRIDE], __popcll(m));
     base = __shfl(base, 0);
     if (pass) {
         // first-index maximum; a NaN beats every number and the first NaN wins
         float best = r[5];
         int bi = 0;
+#pragma unroll 8
         for (int j = 1; j < C; ++j) {
             float v = r[5 + j];
             if ((v > best) || ((v != v) && !(best != best))) { best = v; bi = j; }
@@ -204,7 +223,7 @@ nms_sort_kernel(const int* __restrict__ cand_count, int key_stride, int C,
                 int* __restrict__ total_tiles) {
     __shared__ unsigned long long skeys[SORT_LDS_KEYS];
     const int b = blockIdx.x;
-    const int cnt = cand_count[b];
+    const int cnt = cand_count[b * CNT_STRIDE];
     unsigned long long* gk = keys + (size_t)b * key_stride;
     for (int c = threadIdx.x; c < C; c += SORT_THREADS) {
         seg_start[b * C + c] = 0;
@@ -522,7 +541,7 @@ rows8_gather_kernel(const unsigned long long* __restrict__ keys, const int* __re
 
 // ---------------------------------------------------------------- workspace
 struct NmsWorkspace {
-    int* cand_count;     // [B]
+    int* cand_count;     // [B][CNT_STRIDE], one counter per 128-byte line
     int* total;          // [1]  (lives in the caller's out_count instead when given)
     int* seg_start;      // [B*C]
     int* seg_end;        // [B*C]
@@ -547,7 +566,7 @@ static NmsWorkspace carve(void* base, int B, int N, int C) {
     char* p = (char*)base;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* r = p + off; off = align_up(off + bytes, 256); return r; };
-    w.cand_count = (int*)take(sizeof(int) * (size_t)B);
+    w.cand_count = (int*)take(sizeof(int) * (size_t)B * CNT_STRIDE);
     w.zero_bytes = off;
     w.total = (int*)take(sizeof(int));
     const size_t S = (size_t)B * C;
@@ -601,16 +620,16 @@ extern "C" int yolo_amd_filter_results(const float* pred, int B, int N, int D, i
     YA_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, stream));
 
     // compact: LDS per wave = 64*D floats; fewer waves per block for wide rows
-    const size_t wave_lds = (size_t)64 * D * sizeof(float);
+    const size_t wave_lds = align_up((size_t)64 * D * sizeof(float) + 16, 16);
     YA_REQUIRE(wave_lds <= 150 * 1024, "filter_results: D=%d rows do not fit the LDS tile", D);
     if (wave_lds * 2 <= 64 * 1024) {
         dim3 grid((N + 127) / 128, B);
         hipLaunchKernelGGL(nms_compact_kernel<2>, grid, dim3(128), wave_lds * 2, stream, pred, N, D, C,
-                           conf, w.key_stride, w.cand_count, w.keys, w.boxes, w.scores);
+                           conf, w.key_stride, (int)wave_lds, w.cand_count, w.keys, w.boxes, w.scores);
     } else {
         dim3 grid((N + 63) / 64, B);
         hipLaunchKernelGGL(nms_compact_kernel<1>, grid, dim3(64), wave_lds, stream, pred, N, D, C,
-                           conf, w.key_stride, w.cand_count, w.keys, w.boxes, w.scores);
+                           conf, w.key_stride, (int)wave_lds, w.cand_count, w.keys, w.boxes, w.scores);
     }
     hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(SORT_THREADS), 0, stream, w.cand_count,
                        w.key_stride, C, w.keys, w.seg_start, w.seg_end, w.tile_base, w.mask_off,
