@@ -477,30 +477,32 @@ conv_igemm_kernel(const ConvArgs a) {
 
 // ---------------------------------------------------------------- 3x3 with patch reuse
 // Stride-1 3x3 layers re-read every input pixel nine times when each tap is
-// staged as its own im2col tile, and the CU's vector-memory path (not the
-// MFMA pipe) becomes the limit.  This kernel stages, per 32-channel chunk, the
-// (13+2)x(13+2) input PATCH of a 13x13 output tile once and feeds all nine
+// staged as its own im2col tile, and the CU's vector-memory path (64 B/clk, and
+// every 1 KiB LDS-DMA instruction costs its wave 60-180 cycles of issue), not
+// the MFMA pipe, becomes the limit.  This kernel stages, per 32-channel chunk,
+// the (13+2)x(13+2) input PATCH of a 13x13 output tile once and feeds all nine
 // taps from it, so only the weights are streamed per tap:
-//   bytes filled per chunk  = 14 KB patch + 9 x 8 KB weights   (was 9 x 16 KB)
-// and with two spatial tiles per workgroup the weight stream is shared too.
+//   LDS-DMA instructions per wave per chunk = 4 (patch) + 9 x 2 (weights) = 22
+//   for 198 MFMAs, against 1 per 4 MFMAs in the im2col kernel.
 //
-// Workgroup = TILES spatial tiles x 128 output channels, 4*TILES waves; wave
-// (t, cg) owns all 11 pixel groups (176 slots for the 169 pixels) of tile t for
-// channels cg*32..+32.
+// Workgroup = one 13x13 spatial tile x 128 output channels, 4 waves; wave cg
+// owns all 11 pixel groups (176 slots for the 169 pixels) for channels
+// cg*32..+32 (88 accumulator registers).
 //   patch   LDS planes [q = 16-byte chunk 0..3][row 0..15][16 slots], slot of
 //           patch pixel (py, px) = (px + 13*py) mod 16 in row py: for every tap
 //           the 16 lanes of a pixel group then read 16 distinct bank slots.
-//           Filled through registers (coalesced 64-byte pixel reads, then
-//           ds_write), double buffered, loads issued two K-iterations early.
-//   weights LDS-DMA ring of (chunk, kw) stages = 3 taps (kh) x 128 channels x
-//           32 k, XOR-swizzled rows as in conv_layout.h, counted vmcnt waits.
+//           Wave w fills plane w with four LDS-DMA instructions (4 rows each),
+//           double buffered, issued one per tap during the previous chunk.
+//   weights LDS-DMA ring of two (chunk, tap) stages = 128 channels x 32 k,
+//           XOR-swizzled rows as in conv_layout.h, counted vmcnt waits.
+// 48 KiB of LDS and <= 168 registers: three workgroups per CU.
 // 13 divides every feature-map side of a 416-pixel input (13 * 2^n).
 constexpr int P3_TS = 13;                  // spatial tile side
 constexpr int P3_NPIX = P3_TS * P3_TS;     // 169 output pixels per tile
 constexpr int P3_TP = 11;                  // pixel groups of 16 (176 slots)
 constexpr int P3_PLANE = 256 * 16;         // bytes per patch plane (16 rows x 16 slots x 16 B)
-constexpr int P3_PATCH = 4 * P3_PLANE;     // 16 KiB per (tile, buffer)
-constexpr int P3_WSTAGE = 3 * 128 * 64;    // 24 KiB: 3 taps x 128 channels x 32 bf16
+constexpr int P3_PATCH = 4 * P3_PLANE;     // 16 KiB per buffer
+constexpr int P3_WSTAGE = 128 * 64;        // 8 KiB: 128 channels x 32 bf16
 
 struct Conv3Args {
     const __bf16* src;
@@ -512,50 +514,31 @@ struct Conv3Args {
     int C, H, W, Cout, K;
     int leaky, dst_fp32;
     int tiles_y, tiles_x, ntiles;      // spatial tiles per image (y, x) and in the batch
-    int tiles_m, tiles_n;              // workgroup grid: tile groups x channel tiles
+    int tiles_n;                       // channel tiles
 };
 
-template <int X>
-__device__ __forceinline__ void p3_wait() { wait_vmcnt<X>(); }
-
-template <int TILES>
-__global__ void __launch_bounds__(256 * TILES)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 conv3x3_patch_kernel(const Conv3Args a) {
-    constexpr int NW = 4 * TILES;              // waves
-    constexpr int NSTG = TILES == 2 ? 3 : 2;   // weight ring depth
-    constexpr int PRE = NSTG - 1;
-    constexpr int LW = 24 / NW;                // weight LDS-DMA instructions per wave per stage
-    constexpr int LP = 4;                      // patch loads per wave per chunk
-    constexpr int PATCH_TOTAL = 2 * TILES * P3_PATCH;
-    __shared__ __attribute__((aligned(1024))) char lds[PATCH_TOTAL + NSTG * P3_WSTAGE];
-    char* wring = lds + PATCH_TOTAL;
+    __shared__ __attribute__((aligned(1024))) char lds[2 * P3_PATCH + 2 * P3_WSTAGE];
+    char* const wring = lds + 2 * P3_PATCH;
 
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = w >> 2, cg = w & 3;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = channel group and patch plane
 
     int tile;
     {
-        const int T = a.tiles_m * a.tiles_n;
+        const int T = a.ntiles * a.tiles_n;
         const int q8 = T >> 3, r8 = T & 7;
         const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     }
-    const int tile_n = tile % a.tiles_n, tb = tile / a.tiles_n;
+    const int tile_n = tile % a.tiles_n, gt = tile / a.tiles_n;
     const int n0 = tile_n * 128;
     const int per_img = a.tiles_y * a.tiles_x;
+    const int cb = gt / per_img;
+    const int oy0 = ((gt - cb * per_img) / a.tiles_x) * P3_TS;
+    const int ox0 = ((gt - cb * per_img) % a.tiles_x) * P3_TS;
 
-    // ---- the spatial tile this wave computes
-    const int gt = tb * TILES + t;
-    const bool tvalid = gt < a.ntiles;
-    int cb = 0, oy0 = 0, ox0 = 0;
-    if (tvalid) {
-        cb = gt / per_img;
-        const int rem = gt - cb * per_img;
-        const int tyi = rem / a.tiles_x;
-        oy0 = tyi * P3_TS;
-        ox0 = (rem - tyi * a.tiles_x) * P3_TS;
-    }
     const int r = lane & 15, q = lane >> 4;
     int tyb[P3_TP];                            // byte offset of (plane q, patch row ty) per pixel group
 #pragma unroll
@@ -563,59 +546,33 @@ conv3x3_patch_kernel(const Conv3Args a) {
         const int p = min(tp * 16 + r, P3_NPIX - 1);
         tyb[tp] = q * P3_PLANE + (p / P3_TS) * 256;
     }
-    const int wfrag = slot_of<32>(r, q) * 16;
+    const int wfrag = (w * 32) * 64 + slot_of<32>(r, q) * 16;
 
-    // ---- patch fill: LP rows (of 16 pixels x 4 chunks) per wave per chunk
-    const int fpx = lane >> 2, fq = lane & 3;
-    int poff[LP], pdst[LP];
+    // ---- patch fill: instruction i of this wave = rows 4i..4i+3 of plane w
+    int poff[4];
 #pragma unroll
-    for (int i = 0; i < LP; ++i) {
-        const int j = w + i * NW;              // row number across the TILES patches
-        const int tf = j >> 4, py = j & 15;
-        const int gtf = tb * TILES + tf;
-        int off = -1;
-        if (tf < TILES && gtf < a.ntiles && py < P3_TS + 2 && fpx < P3_TS + 2) {
-            const int fb = gtf / per_img;
-            const int rem = gtf - fb * per_img;
-            const int tyi = rem / a.tiles_x;
-            const int iy = tyi * P3_TS - 1 + py;
-            const int ix = (rem - tyi * a.tiles_x) * P3_TS - 1 + fpx;
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) off = ((fb * a.H + iy) * a.W + ix) * a.C + fq * 8;
-        }
-        poff[i] = off;
-        pdst[i] = (tf < TILES ? tf : 0) * P3_PATCH + fq * P3_PLANE + (py * 16 + ((fpx + P3_TS * py) & 15)) * 16;
+    for (int i = 0; i < 4; ++i) {
+        const int py = 4 * i + q, slot = r;
+        const int px = (slot - P3_TS * py) & 15;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        poff[i] = (py < P3_TS + 2 && px < P3_TS + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                      ? ((cb * a.H + iy) * a.W + ix) * a.C + w * 8
+                      : -1;
     }
-    // ---- weight fill: LW LDS-DMA instructions per wave per (chunk, kw) stage
+    // ---- weight fill: two LDS-DMA instructions per wave per (chunk, tap) stage
     const int cout_pad = a.tiles_n * 128;
-    int woff[LW];
+    int woff[2];
     {
         const int qw = (lane & 3) ^ chunk_swizzle<32>(lane >> 2);
 #pragma unroll
-        for (int i = 0; i < LW; ++i) {
-            const int j = w + i * NW;          // 0..23: kh = j / 8, 16 channel rows each
-            const int kh = j >> 3, n = (j & 7) * 16 + (lane >> 2);
-            woff[i] = ((kh * 3 * a.C / 32) * cout_pad + n0 + n) * 32 + qw * 8;   // [K/32][cout_pad][32]
-        }
+        for (int i = 0; i < 2; ++i) woff[i] = (n0 + (w * 2 + i) * 16 + (lane >> 2)) * 32 + qw * 8;
     }
-    auto issue_w = [&](int it) {               // stage `it` = (chunk it/3, kw it%3)
-        const int chunk = it / 3, kw = it - chunk * 3;
-        const int delta = (kw * a.C + chunk * 32) * cout_pad;
-        char* dst = wring + (it % NSTG) * P3_WSTAGE;
+    const int wstep_tap = (a.C / 32) * cout_pad * 32;     // [K/32][cout_pad][32]: one tap further
+    const int wstep_chunk = cout_pad * 32;
+    auto issue_w = [&](int chunk, int tap, int buf) {
+        const int delta = tap * wstep_tap + chunk * wstep_chunk;
 #pragma unroll
-        for (int i = 0; i < LW; ++i) lds_dma16(a.wgt + (woff[i] + delta), dst + (w + i * NW) * 1024);
-    };
-    bf16x8 preg[LP];
-    auto load_patch = [&](int chunk) {
-#pragma unroll
-        for (int i = 0; i < LP; ++i) {
-            const __bf16* p = poff[i] >= 0 ? a.src + (poff[i] + chunk * 32) : a.zero;
-            preg[i] = *reinterpret_cast<const bf16x8*>(p);
-        }
-    };
-    auto store_patch = [&](int buf) {
-        char* base = lds + buf * (TILES * P3_PATCH);
-#pragma unroll
-        for (int i = 0; i < LP; ++i) *reinterpret_cast<bf16x8*>(base + pdst[i]) = preg[i];
+        for (int i = 0; i < 2; ++i) lds_dma16(a.wgt + (woff[i] + delta), wring + buf * P3_WSTAGE + (w * 2 + i) * 1024);
     };
 
     f32x4 acc[2][P3_TP];
@@ -624,80 +581,89 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
         for (int tp = 0; tp < P3_TP; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int NCH = a.C / 32, KI = NCH * 3;
-    load_patch(0);
-    store_patch(0);
+    const int NCH = a.C / 32;
 #pragma unroll
-    for (int s = 0; s < PRE; ++s)
-        if (s < KI) issue_w(s);
+    for (int i = 0; i < 4; ++i) {
+        const __bf16* p = poff[i] >= 0 ? a.src + poff[i] : a.zero;
+        lds_dma16(p, lds + w * P3_PLANE + i * 1024);
+    }
+    issue_w(0, 0, 0);
+    bool patch_behind = false;                 // a patch load was issued after the weights now awaited
+    int buf = 0;
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        const char* pb = lds + (chunk & 1) * P3_PATCH;
+        const bool more_chunks = chunk + 1 < NCH;
+        int kh = 0, kw = 0;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            if (patch_behind) wait_vmcnt<1>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // next stage's weights first (they are awaited first), then one
+            // instruction of the next chunk's patch
+            if (tap < 8) issue_w(chunk, tap + 1, buf ^ 1);
+            else if (more_chunks) issue_w(chunk + 1, 0, buf ^ 1);
+            patch_behind = tap < 4 && more_chunks;
+            if (patch_behind) {
+                // (instruction `tap` of the four; written out because the loop is not unrolled)
+                const int po = tap == 0 ? poff[0] : tap == 1 ? poff[1] : tap == 2 ? poff[2] : poff[3];
+                const __bf16* pp = po >= 0 ? a.src + (po + (chunk + 1) * 32) : a.zero;
+                lds_dma16(pp, lds + ((chunk + 1) & 1) * P3_PATCH + w * P3_PLANE + tap * 1024);
+            }
 
-    int chunk = 0, kw = 0;
-    for (int it = 0; it < KI; ++it) {
-        // loads younger than weight stage `it`: later weight stages already
-        // issued, and the patch loads issued (after the weight stage) at kw == 0
-        // inside the last PRE iterations
-        const int nW = min(PRE - 1, KI - 1 - it);
-        bool nP = false;
-#pragma unroll
-        for (int back = 1; back <= PRE; ++back) {
-            const int j = it - back;
-            if (j >= 0 && j % 3 == 0 && j / 3 + 1 < NCH) nP = true;
-        }
-        if (PRE == 2 && nW == 1) { if (nP) p3_wait<LW + LP>(); else p3_wait<LW>(); }
-        else { if (nP) p3_wait<LP>(); else p3_wait<0>(); }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's patch ds_writes are done
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kw == 2 && chunk + 1 < NCH) store_patch((chunk + 1) & 1);
-        if (it + PRE < KI) issue_w(it + PRE);
-        asm volatile("" ::: "memory");
-        if (kw == 0 && chunk + 1 < NCH) load_patch(chunk + 1);
-
-        const char* pb = lds + (chunk & 1) * (TILES * P3_PATCH) + t * P3_PATCH;
-        const char* ws = wring + (it % NSTG) * P3_WSTAGE + (cg * 32) * 64 + wfrag;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
             const int colb = ((r + kw + P3_TS * kh) & 15) * 16 + kh * 256;
-            bf16x8 wf[2], xf[P3_TP];
+            const char* ws = wring + buf * P3_WSTAGE + wfrag;
+            bf16x8 wf[2];
 #pragma unroll
-            for (int tc = 0; tc < 2; ++tc)
-                wf[tc] = *reinterpret_cast<const bf16x8*>(ws + kh * 8192 + tc * 1024);
+            for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
+            {
+                bf16x8 xf[6];
 #pragma unroll
-            for (int tp = 0; tp < P3_TP; ++tp)
-                xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
+                for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
 #pragma unroll
-            for (int tp = 0; tp < P3_TP; ++tp)
+                for (int tp = 0; tp < 6; ++tp)
 #pragma unroll
-                for (int tc = 0; tc < 2; ++tc)
-                    acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+                    for (int tc = 0; tc < 2; ++tc)
+                        acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                bf16x8 xf[5];
+#pragma unroll
+                for (int tp = 0; tp < 5; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[6 + tp] + colb);
+#pragma unroll
+                for (int tp = 0; tp < 5; ++tp)
+#pragma unroll
+                    for (int tc = 0; tc < 2; ++tc)
+                        acc[tc][6 + tp] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][6 + tp], 0, 0, 0);
+            }
+            buf ^= 1;
+            if (++kw == 3) { kw = 0; ++kh; }
         }
-        if (++kw == 3) { kw = 0; ++chunk; }
     }
 
     // ---- epilogue
     const int cq = q * 4;
     if (!a.dst_fp32 && (a.Cout & 7) == 0) {
-        constexpr int NSLOT = TILES * 176;
+        constexpr int NSLOT = 176;
         auto pix = [&](int slot) -> long long {
-            const int tt = slot / 176, p = slot - tt * 176;
-            const int g = tb * TILES + tt;
-            if (p >= P3_NPIX || g >= a.ntiles) return -1;
-            const int b = g / per_img, rem = g - b * per_img;
-            const int tyi = rem / a.tiles_x, txi = rem - tyi * a.tiles_x;
-            const int ty = p / P3_TS, tx = p - ty * P3_TS;
-            return ((long long)b * a.H + tyi * P3_TS + ty) * a.W + txi * P3_TS + tx;
+            if (slot >= P3_NPIX) return -1;
+            const int ty = slot / P3_TS, tx = slot - ty * P3_TS;
+            return ((long long)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
         };
         __syncthreads();
         if (a.res) {
-            tile_load_residual<NSLOT, 128, 256 * TILES>(lds, a.res, a.zero, a.Cout, n0, w, lane, pix);
+            tile_load_residual<NSLOT, 128, 256>(lds, a.res, a.zero, a.Cout, n0, w, lane, pix);
             __syncthreads();
         }
 #pragma unroll
         for (int tp = 0; tp < P3_TP; ++tp) {
-            const int slot = t * 176 + tp * 16 + r;
+            const int slot = tp * 16 + r;
 #pragma unroll
             for (int tc = 0; tc < 2; ++tc) {
-                const int chl = cg * 32 + tc * 16 + cq;
+                const int chl = w * 32 + tc * 16 + cq;
                 const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + chl);
                 float v[4];
 #pragma unroll
@@ -710,10 +676,9 @@ conv3x3_patch_kernel(const Conv3Args a) {
             }
         }
         __syncthreads();
-        tile_store<NSLOT, 128, 256 * TILES>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
+        tile_store<NSLOT, 128, 256>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
         return;
     }
-    if (!tvalid) return;
 #pragma unroll
     for (int tp = 0; tp < P3_TP; ++tp) {
         const int p = tp * 16 + r;
@@ -722,21 +687,15 @@ conv3x3_patch_kernel(const Conv3Args a) {
         const size_t m = ((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
 #pragma unroll
         for (int tc = 0; tc < 2; ++tc) {
-            const int ch = n0 + cg * 32 + tc * 16 + cq;
+            const int ch = n0 + w * 32 + tc * 16 + cq;
             if (ch >= a.Cout) continue;
             const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + ch);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = acc[tc][tp][e] + bs[e];
-                if (a.leaky) x = x > 0.f ? x : 0.1f * x;
-                v[e] = x;
-            }
             const size_t o = m * a.Cout + ch;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (ch + e >= a.Cout) break;
-                float x = v[e];
+                float x = acc[tc][tp][e] + bs[e];
+                if (a.leaky) x = x > 0.f ? x : 0.1f * x;
                 if (a.res) x += (float)a.res[o + e];
                 if (a.dst_fp32) ((float*)a.dst)[o + e] = x;
                 else ((__bf16*)a.dst)[o + e] = (__bf16)x;
@@ -1004,13 +963,7 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.C = d.c0; p.H = d.H; p.W = d.W; p.Cout = d.cout; p.K = K; p.leaky = d.leaky; p.dst_fp32 = d.dst_fp32;
         p.tiles_y = d.H / P3_TS; p.tiles_x = d.W / P3_TS; p.ntiles = d.B * p.tiles_y * p.tiles_x;
         p.tiles_n = d.cout_pad / 128;
-        int tiles = env_int("YOLO_AMD_CONV3_TILES", 0);
-        if (tiles != 1 && tiles != 2) tiles = 1;
-        p.tiles_m = (p.ntiles + tiles - 1) / tiles;
-        if (tiles == 2)
-            hipLaunchKernelGGL(conv3x3_patch_kernel<2>, dim3(p.tiles_m * p.tiles_n), dim3(512), 0, stream, p);
-        else
-            hipLaunchKernelGGL(conv3x3_patch_kernel<1>, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(conv3x3_patch_kernel, dim3(p.ntiles * p.tiles_n), dim3(256), 0, stream, p);
         return YA_OK;
     }
     ConvArgs a;
