@@ -35,6 +35,11 @@ LAYERS = [
     ("1x1 512->256 @26", 26, 512, 256, 1, 1, False),
     ("1x1 1024->512 @13", 13, 1024, 512, 1, 1, False),
     ("1x1 256->255 @52 fp32", 52, 256, 255, 1, 1, False),
+    # almost no K loop: what a launch costs in set-up, epilogue and tail
+    ("ovh 1x1 32->512 @26 res", 26, 32, 512, 1, 1, True),
+    ("ovh 1x1 32->512 @26", 26, 32, 512, 1, 1, False),
+    ("ovh 1x1 32->128 @26", 26, 32, 128, 1, 1, False),
+    ("ovh 3x3 32->512 @26 res", 26, 32, 512, 3, 1, True),
     # non-power-of-two channel counts: does the pixel pitch matter?
     ("pitch 1x1 1088->512 @13", 13, 1088, 512, 1, 1, False),
     ("pitch 1x1 960->512 @13", 13, 960, 512, 1, 1, False),

@@ -954,9 +954,15 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     YA_REQUIRE(d.cout_pad % BN == 0 && d.cout_pad >= d.cout, "conv: cout_pad=%d not a multiple of %d", d.cout_pad, BN);
     YA_REQUIRE((long long)d.B * d.H * d.W * (d.c0 + d.c1) < (1ll << 31) && (long long)d.cout_pad * K < (1ll << 31),
                "conv: tensor too large for 32-bit element offsets");
-    // stride-1 3x3 layers on 13*2^n feature maps: the patch-reuse kernel
+    // Stride-1 3x3 layers on 13*2^n feature maps can take the patch-reuse kernel.
+    // It wins where its 13x13-pixel tiles give at least ~4 workgroups per CU
+    // (measured: 104x104 and 52x52 maps at batch 32); on smaller maps the 128-
+    // pixel tiles of the im2col kernel fill the GPU better.  YOLO_AMD_CONV3=0/1
+    // forces the choice (development knob).
+    const long long p3_groups = (long long)d.B * (d.H / P3_TS) * (d.W / P3_TS) * (d.cout_pad / 128);
+    const int p3 = env_int("YOLO_AMD_CONV3", -1);
     if (d.ksize == 3 && d.stride == 1 && d.c1 == 0 && d.up0 == 0 && d.H % P3_TS == 0 && d.W % P3_TS == 0 &&
-        d.cout_pad % 128 == 0 && env_int("YOLO_AMD_CONV3", 0)) {
+        d.cout_pad % 128 == 0 && (p3 == 1 || (p3 < 0 && p3_groups >= 1000))) {
         Conv3Args p;
         p.src = (const __bf16*)d.src0; p.wgt = (const __bf16*)d.weight; p.bias = d.bias;
         p.res = (const __bf16*)d.residual; p.dst = d.dst; p.zero = (const __bf16*)zero_page;
