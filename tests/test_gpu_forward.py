@@ -218,9 +218,13 @@ def test_forward_layers_and_output(case):
     assert np.abs(got[..., 4] - want[..., 4]).max() < 0.05
 
 
-def test_forward_416_vs_oracle_and_end_to_end():
+@pytest.mark.parametrize("conv3", ["0", "1"], ids=["im2col", "patch-reuse"])
+def test_forward_416_vs_oracle_and_end_to_end(conv3, monkeypatch):
+    """Whole network at full size, with the stride-1 3x3 layers forced through each of
+    their two kernels (at batch 32 the large maps take the patch-reuse one by default)."""
     from gpu_helpers import build_model, oracle_forward
     from yolo_amd.utilis import filter_results
+    monkeypatch.setenv("YOLO_AMD_CONV3", conv3)
     model, params, sd = build_model(416)
     x_np = gi.images(9, 1, 416)
     det = model(torch.from_numpy(x_np).cuda())
