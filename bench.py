@@ -176,6 +176,15 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
         achieved = flops_per_batch / (conv_ms * 1e-3) / 1e12
+        # HBM-side bytes of the conv stack from the PMC passes of tools/pmc_bench.sh over this
+        # same command (the profiler cannot run inside the timed region); null when the file is
+        # absent or was taken for another batch size
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "round1_conv_traffic.json")
+        if os.path.exists(tpath) and (B, H) == (32, 416):
+            with open(tpath) as fh:
+                traffic = round(json.load(fh)["hbm_bytes_per_launch"])
+            traffic_src = "profiles/round1_conv_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per conv launch)"
         n_convs = len(plan.ops)
         N = plan.N
         result = {
@@ -190,7 +199,8 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2),
                          "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": f"conv stack ({n_convs} fused conv launches per step)",
                          "flop_per_launch_avg": flops_per_batch / n_convs,
                          "avg_launch_ms": round(conv_ms / n_convs, 5)},
