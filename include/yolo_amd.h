@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YOLO_AMD_ABI_VERSION 1
+#define YOLO_AMD_ABI_VERSION 2
 #define YOLO_AMD_MAX_HEADS 4
 #define YOLO_AMD_MAX_ANCHORS 8
 
@@ -123,6 +123,16 @@ typedef struct {
     int leaky;            /* apply LeakyReLU(0.1)                               */
     int dst_fp32;         /* 1: dst is fp32 (detection convs), 0: bf16          */
     int first_layer;      /* 1: src0 is the NCHW fp32 network input             */
+    /* Detection convolutions can run yolo_v3.predict in their epilogue
+     * (/root/reference/yolo_v3.py:205-262) instead of leaving it to
+     * yolo_amd_decode: with decode != NULL (host pointer; needs dst_fp32,
+     * cout == decode_anchors * D, H == W == decode->G, no residual), dst is the
+     * (B, decode_rows, D) prediction tensor and this layer writes its rows
+     * decode->row_offset .. + G*G*decode_anchors, already decoded;
+     * decode->raw and decode->layout are not used. */
+    const yolo_amd_head_desc* decode;
+    int decode_rows;      /* N_total of the prediction tensor                   */
+    int decode_anchors;   /* A                                                  */
 } yolo_amd_conv_desc;
 
 /* Output channels are padded to a whole channel tile: returns the padded

@@ -47,6 +47,9 @@ class ConvDesc(ctypes.Structure):
         ("leaky", ctypes.c_int),
         ("dst_fp32", ctypes.c_int),
         ("first_layer", ctypes.c_int),
+        ("decode", ctypes.POINTER(HeadDesc)),
+        ("decode_rows", ctypes.c_int),
+        ("decode_anchors", ctypes.c_int),
     ]
 
 
@@ -92,7 +95,7 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    want = 1
+    want = 2
     got = lib.yolo_amd_abi_version()
     if got != want:
         raise ImportError(f"{LIB_PATH} has ABI version {got}, the Python side expects {want}")

@@ -59,4 +59,15 @@ __device__ __forceinline__ uint32_t fdiv_u32(uint32_t n, FastDiv f) {
     return (hi + ((n - hi) >> 1)) >> (f.shift - 1);
 }
 
+// One element of yolo_v3.predict (/root/reference/yolo_v3.py:205-262) for
+// channel d of a box at grid cell (gx, gy): shared by the decode kernel and by
+// the detection convolutions that decode in their epilogue, so both give the
+// same bits.  anc = anchor width (d == 2) or height (d == 3) in grid units.
+__device__ __forceinline__ float sigmoid_ref(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
+__device__ __forceinline__ float decode_value(float x, int d, float gx, float gy, float anc, float stride) {
+    if (d >= 4) return sigmoid_ref(x);
+    if (d < 2) return __fmul_rn(__fadd_rn(sigmoid_ref(x), d == 0 ? gx : gy), stride);
+    return __fmul_rn(__fmul_rn(expf(x), anc), stride);
+}
+
 }  // namespace yolo_amd

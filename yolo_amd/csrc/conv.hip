@@ -47,6 +47,11 @@ struct ConvArgs {
     int leaky, dst_fp32;
     int tiles_m, tiles_n;
     FastDiv divHoWo, divWo;
+    // fused head decode (dec_D > 0): dst is the (B, dec_rows, dec_D) prediction tensor
+    int dec_D, dec_rows, dec_row_offset;
+    float dec_stride;
+    float dec_aw[YOLO_AMD_MAX_ANCHORS], dec_ah[YOLO_AMD_MAX_ANCHORS];
+    FastDiv divD;
 };
 
 
@@ -401,6 +406,90 @@ conv_igemm_kernel(const ConvArgs a) {
 
     // ---- epilogue: bias, LeakyReLU, residual, store
     const int px = lane & 15, cq = (lane >> 4) * 4;
+    if (a.dst_fp32 && !a.res) {
+        // fp32 output (the detection convolutions, 255 channels: rows of 1020
+        // bytes).  The tile goes through LDS 32 channels at a time so that the
+        // stores are runs of 128 contiguous bytes per pixel, and the head decode
+        // (yolo_v3.predict), when asked for, is applied on the way out.
+        constexpr int PC = 32, PITCH = PC + 4;            // +4 floats: the 16 pixel rows of a b128 write hit distinct banks
+        float* const tile = reinterpret_cast<float*>(lds);
+        float* const geo = tile + BM * PITCH;              // per tile pixel: destination offset, gx, gy
+        __syncthreads();                                   // operand stages are dead from here on
+        if (threadIdx.x < BM) {
+            const int m = m0 + threadIdx.x;
+            long long off = -1;
+            float gx = 0.f, gy = 0.f;
+            if (m < a.M) {
+                if (a.dec_D) {
+                    const uint32_t b = fdiv_u32((uint32_t)m, a.divHoWo);
+                    const uint32_t pix = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+                    const uint32_t oy = fdiv_u32(pix, a.divWo);
+                    gx = (float)(int)(pix - oy * (uint32_t)a.Wo);
+                    gy = (float)(int)oy;
+                    off = ((long long)b * a.dec_rows + a.dec_row_offset) * a.dec_D + (long long)pix * a.Cout;
+                } else {
+                    off = (long long)m * a.Cout;
+                }
+            }
+            reinterpret_cast<long long*>(geo)[threadIdx.x] = off;     // 8-byte slots first ...
+            geo[2 * BM + threadIdx.x] = gx;                            // ... then gx, gy
+            geo[3 * BM + threadIdx.x] = gy;
+        }
+        static_assert(BM * PITCH * 4 + BM * 16 <= LDS_BYTES, "fp32 epilogue tile and pixel table do not fit");
+        const int ch_l = threadIdx.x & (PC - 1), sub = threadIdx.x / PC;
+        constexpr int SUBS = 256 / PC;
+#pragma unroll 1
+        for (int p = 0; p < BN / PC; ++p) {
+            const int c_lo = p * PC;
+            if (wn == c_lo / WNC) {
+                const int tc0 = (c_lo % WNC) / 16;
+#pragma unroll
+                for (int tp = 0; tp < TP; ++tp) {
+                    const int slot = wm * WMP + tp * 16 + px;
+#pragma unroll
+                    for (int t = 0; t < PC / 16; ++t) {
+                        f32x4 v = acc[0][tp];
+                        // (static accumulator indices: tc0 is 0 or 2 for 64-channel waves, 0 for 32-channel ones)
+#pragma unroll
+                        for (int tc = 0; tc < TC; ++tc)
+                            if (tc == tc0 + t) v = acc[tc][tp];
+                        const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + c_lo + t * 16 + cq);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = v[r] + bs[r];
+                            if (a.leaky) x = x > 0.f ? x : 0.1f * x;
+                            v[r] = x;
+                        }
+                        *reinterpret_cast<f32x4*>(tile + slot * PITCH + t * 16 + cq) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            const int ch = n0 + c_lo + ch_l;
+            if (ch < a.Cout) {
+                int d = 0;
+                float anc = 0.f;
+                if (a.dec_D) {
+                    const int ai = (int)fdiv_u32((uint32_t)ch, a.divD);
+                    d = ch - ai * a.dec_D;
+                    anc = d == 2 ? a.dec_aw[ai] : a.dec_ah[ai];
+                }
+                float* const dstf = reinterpret_cast<float*>(a.dst);
+#pragma unroll 4
+                for (int i = 0; i < BM / SUBS; ++i) {
+                    const int slot = i * SUBS + sub;
+                    const long long off = reinterpret_cast<const long long*>(geo)[slot];
+                    if (off >= 0) {
+                        float v = tile[slot * PITCH + ch_l];
+                        if (a.dec_D) v = decode_value(v, d, geo[2 * BM + slot], geo[3 * BM + slot], anc, a.dec_stride);
+                        dstf[off + ch] = v;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     if (!a.dst_fp32 && (a.Cout & 7) == 0) {
         auto pix = [&](int slot) -> long long { return m0 + slot < a.M ? (long long)(m0 + slot) : -1; };
         __syncthreads();                       // operand stages are dead from here on
@@ -987,6 +1076,23 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     a.C0 = d.c0; a.C1 = d.c1; a.up0 = d.up0; a.H = d.H; a.W = d.W; a.Ho = Ho; a.Wo = Wo; a.M = (int)M;
     a.Cout = d.cout; a.Kpad = K; a.ksize = d.ksize; a.stride = d.stride; a.leaky = d.leaky;
     a.dst_fp32 = d.dst_fp32;
+    a.dec_D = 0; a.dec_rows = 0; a.dec_row_offset = 0; a.dec_stride = 0.f;
+    a.divD = make_fastdiv(1u);
+    for (int i = 0; i < YOLO_AMD_MAX_ANCHORS; ++i) a.dec_aw[i] = a.dec_ah[i] = 0.f;
+    if (d.decode) {
+        const yolo_amd_head_desc& hd = *d.decode;
+        const int A = d.decode_anchors;
+        YA_REQUIRE(d.dst_fp32 && !d.residual && A >= 1 && A <= YOLO_AMD_MAX_ANCHORS && d.cout % A == 0 &&
+                       d.cout / A >= 5 && Ho == Wo && hd.G == Ho,
+                   "conv: fused decode needs an fp32, residual-free layer with cout = A*D on a GxG map");
+        YA_REQUIRE(hd.row_offset >= 0 && hd.row_offset + Ho * Wo * A <= d.decode_rows,
+                   "conv: fused decode rows [%d, %d) fall outside %d", hd.row_offset,
+                   hd.row_offset + Ho * Wo * A, d.decode_rows);
+        a.dec_D = d.cout / A; a.dec_rows = d.decode_rows; a.dec_row_offset = hd.row_offset;
+        a.dec_stride = hd.stride;
+        for (int i = 0; i < A; ++i) { a.dec_aw[i] = hd.anchor_w[i]; a.dec_ah[i] = hd.anchor_h[i]; }
+        a.divD = make_fastdiv((uint32_t)a.dec_D);
+    }
     constexpr int BM = 128;
     a.tiles_m = (int)((M + BM - 1) / BM);
     a.tiles_n = d.cout_pad / BN;

@@ -36,8 +36,6 @@ struct DecodeArgs {
     int blocks_per_head[YOLO_AMD_MAX_HEADS + 1];   // prefix sums of blocks along grid.x
 };
 
-__device__ __forceinline__ float sigmoid_ref(float x) { return __fdiv_rn(1.0f, 1.0f + expf(-x)); }
-
 constexpr int DEC_THREADS = 256;
 constexpr int DEC_PER_THREAD = 4;
 
@@ -67,18 +65,13 @@ decode_kernel(DecodeArgs args, float* __restrict__ out) {
         } else {
             x = in[(size_t)(a * D + d) * GG + pix];
         }
-        float v;
-        if (d >= 4) {
-            v = sigmoid_ref(x);
-        } else if (d < 2) {
+        float gxf = 0.f, gyf = 0.f;
+        if (d < 2) {
             const uint32_t gy = fdiv_u32(pix, hd.divG);
-            const int gx = (int)pix - (int)gy * hd.G;
-            const float g = (d == 0) ? (float)gx : (float)(int)gy;
-            v = __fmul_rn(__fadd_rn(sigmoid_ref(x), g), hd.stride);
-        } else {
-            const float anc = (d == 2) ? hd.aw[a] : hd.ah[a];
-            v = __fmul_rn(__fmul_rn(expf(x), anc), hd.stride);
+            gxf = (float)((int)pix - (int)gy * hd.G);
+            gyf = (float)(int)gy;
         }
+        const float v = decode_value(x, d, gxf, gyf, d == 2 ? hd.aw[a] : hd.ah[a], hd.stride);
         o[t] = v;
     }
 }

@@ -282,6 +282,19 @@ class Plan:
                 hd.anchor_h[a] = np.float32(layer_anchors[a][1] / stride)
             stride_rows += G * G * self.A
         self.N = stride_rows
+        # The detection convolutions decode in their epilogue and write straight
+        # into the prediction tensor; the separate decode launch remains for plans
+        # that keep the raw head outputs readable (keep_all).
+        self.fused_decode = not self.keep_all
+        self._head_slots = []
+        if self.fused_decode:
+            for k, (bid, G) in enumerate(heads):
+                j = next(j for j, op in enumerate(ops) if f"L{op['index']}" == bid)
+                d = self.descs[j]
+                d.decode = ctypes.pointer(self.head_descs[k])
+                d.decode_rows = self.N
+                d.decode_anchors = self.A
+                self._head_slots.append(j)
 
     def _head_anchors(self, k, anchors):
         idx = [i for i, e in enumerate(self.table) if e["type"] == "yolo"][k]
@@ -334,6 +347,8 @@ class Plan:
             x = x.float()
         self.descs[0].src0 = x.data_ptr()
         out = torch.empty((self.B, self.N, self.D), dtype=torch.float32, device=self.device)
+        for j in self._head_slots:
+            self.descs[j].dst = out.data_ptr()
         with torch.cuda.device(self.device):
             stream = _lib.current_stream_ptr(self.device)
             ev = None
@@ -346,20 +361,14 @@ class Plan:
                                             stream), "conv_forward")
             if ev:
                 ev[1].record()
-            check(lib.yolo_amd_decode(self.head_descs, len(self.heads), self.B, self.A, self.D,
-                                      self.N, out.data_ptr(), stream), "decode")
+            if not self.fused_decode:
+                check(lib.yolo_amd_decode(self.head_descs, len(self.heads), self.B, self.A, self.D,
+                                          self.N, out.data_ptr(), stream), "decode")
             if ev:
                 ev[2].record()
                 self.stage_events.append(ev)
         self._keepalive = x
         return out
-
-    def run_convs_only(self, x):
-        """Conv stack without the decode launch (bench timing of the stages)."""
-        self.descs[0].src0 = x.data_ptr()
-        with torch.cuda.device(self.device):
-            check(lib.yolo_amd_conv_forward(self.descs, len(self.ops), self.zero_page.data_ptr(),
-                                            _lib.current_stream_ptr(self.device)), "conv_forward")
 
     def layer_output(self, index):
         """Debug/test view of a conv output buffer as an NHWC tensor."""
