@@ -91,6 +91,17 @@ int yolo_amd_filter_img_class(const float* rows8, int m, float cls, float nms_th
                               void* workspace, size_t workspace_bytes, float* out_rows8,
                               int* out_count, void* stream);
 
+/* ---------------------------------------------------------------- caller post-processing
+ * Replaces the rescale-and-clamp block the callers run on filter_results'
+ * output           /root/reference/detection.py:52-70, /root/reference/video.py:78-91
+ *
+ * rows9: (K, 9) fp32 rows as written by yolo_amd_filter_results, modified in
+ * place: columns 1-4 go from the letterboxed height x height frame to the
+ * original image of the row (column 0) and are clamped to it.
+ * im_dims: (B, 2) fp32 on the device, original (width, height) per image. */
+int yolo_amd_rescale_boxes(float* rows9, int K, const float* im_dims, int B, float height,
+                           void* stream);
+
 /* ---------------------------------------------------------------- conv stack
  * Replaces the conv / upsample / route / shortcut arms of yolo_v3.forward
  *                                          /root/reference/yolo_v3.py:449-473

@@ -20,6 +20,7 @@ Reference lines restated here:
   box_iou              /root/reference/utilis.py:298-323
   filter_img_class     /root/reference/utilis.py:355-390
   filter_results       /root/reference/utilis.py:393-465
+  rescale block        /root/reference/detection.py:52-70 (= video.py:78-91)
 """
 from __future__ import annotations
 
@@ -362,3 +363,36 @@ def filter_results_torch_loop(prediction, conf, nms_thresh, num_classes):
     if not pieces:
         return 0
     return torch.cat(pieces, 0)
+
+
+# --------------------------------------------------------------------------
+# caller post-processing
+# --------------------------------------------------------------------------
+def rescale_boxes(rows, im_dims, height):
+    """detection.py:52-70: filter_results rows (K, 9) from the letterboxed
+    height x height frame back to each original image (im_dims: (B, 2) = width,
+    height), clamped to it.  fp32 operation by operation; returns a new array.
+    The block is inline in detection() (and video.py), so it is pinned by
+    tests/golden/golden_post.npz, made by torch executing the same statements."""
+    out = np.array(rows, dtype=np.float32, copy=True)
+    if out.shape[0] == 0:
+        return out
+    dims = np.asarray(im_dims, dtype=np.float32)[out[:, 0].astype(np.int64)]     # :53-54
+    hgt = np.float32(height)
+    with np.errstate(all="ignore"):
+        # :55-56  `int / tensor` is Tensor.__rtruediv__ = tensor.reciprocal() * int: two roundings
+        rcp = (np.float32(1) / dims).astype(np.float32)
+        sf = np.minimum(rcp[:, 0] * hgt, rcp[:, 1] * hgt).astype(np.float32)
+        px = ((hgt - sf * dims[:, 0]) / np.float32(2)).astype(np.float32)        # :62-63
+        py = ((hgt - sf * dims[:, 1]) / np.float32(2)).astype(np.float32)        # :64-65
+        for col, pad, lim in ((1, px, dims[:, 0]), (3, px, dims[:, 0]), (2, py, dims[:, 1]), (4, py, dims[:, 1])):
+            v = ((out[:, col] - pad) / sf).astype(np.float32)                    # :66
+            v = np.where(np.isnan(v), v, np.minimum(np.maximum(v, np.float32(0)), lim))   # :67-71, NaN stays NaN
+            out[:, col] = v
+    return out
+
+
+def filter_results_multi(pred, conf_list, nms_thresh, num_classes):
+    """What evaluate.get_map does per batch (evaluate.py:185-192): filter_results
+    once per confidence of the list.  Returns [rows or 0 per confidence]."""
+    return [filter_results(pred, float(c), nms_thresh, num_classes) for c in conf_list]

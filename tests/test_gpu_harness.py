@@ -1,0 +1,85 @@
+"""GPU parity of the caller post-processing (through the C ABI): the rescale-and-clamp
+kernel against the vectors made from the reference's statements and against the
+oracle, and the one-NMS confidence sweep against filter_results at every confidence."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gen_inputs as gi
+import yolo_oracle as orc
+from helpers import assert_bit_equal
+from yolo_amd.cfg import default_params
+
+pytestmark = pytest.mark.gpu
+
+POST = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_post.npz"))
+
+
+@pytest.mark.parametrize("name", ["post_416", "post_608_weird", "post_320_one"])
+def test_rescale_kernel_matches_the_reference_vectors(name):
+    from yolo_amd.harness import rescale_detections
+    rows = torch.from_numpy(POST[name + "_rows"]).cuda()
+    keep = rows.clone()
+    got = rescale_detections(rows, POST[name + "_dims"], int(POST[name + "_height"]))
+    assert torch.equal(rows.view(torch.int32), keep.view(torch.int32)), "the input rows were modified"
+    assert_bit_equal(got.cpu().numpy(), POST[name + "_out"], name)
+    # CPU tensors go through the same kernel and come back on the CPU
+    got_cpu = rescale_detections(torch.from_numpy(POST[name + "_rows"]), POST[name + "_dims"],
+                                 int(POST[name + "_height"]))
+    assert got_cpu.device.type == "cpu"
+    assert_bit_equal(got_cpu.numpy(), POST[name + "_out"], name + " (cpu tensor)")
+    assert rescale_detections(0, POST[name + "_dims"], 416) == 0
+
+
+def test_rescale_kernel_large_vs_oracle():
+    from yolo_amd.harness import rescale_detections
+    r = gi.rs(77)
+    K, B, H = 200_000, 32, 416
+    rows = r.uniform(-50, 470, (K, 9)).astype(np.float32)
+    rows[:, 0] = r.randint(0, B, K)
+    dims = np.stack([r.randint(20, 5000, B), r.randint(20, 5000, B)], 1).astype(np.float32)
+    got = rescale_detections(torch.from_numpy(rows).cuda(), dims, H).cpu().numpy()
+    assert_bit_equal(got, orc.rescale_boxes(rows, dims, H), "200k rows")
+
+
+@pytest.mark.parametrize("mode,ties,C", [("uniform", 0, 80), ("clustered", 0, 6), ("clustered", 7, 6)])
+def test_confidence_sweep_with_one_nms(mode, ties, C):
+    from yolo_amd.harness import detections_by_conf, filter_results_multi
+    from yolo_amd.utilis import filter_results
+    B, N = 3, 1500
+    pred_np = gi.nms_pred(41, B, N, C, H=416, mode=mode, tie_levels=ties)
+    pred = torch.from_numpy(pred_np).cuda()
+    params = default_params(416, C, 3, confidence=0.5, nms_thesh=0.4)
+    confs = list(np.arange(start=0.2, stop=0.95, step=0.025)) + [1.01]      # utilis.py:688, plus an empty one
+    got = filter_results_multi(pred, params, confs)
+    assert len(got) == len(confs)
+    want = orc.filter_results_multi(pred_np, confs, 0.4, C)
+    for c, g, w in zip(confs, got, want):
+        if isinstance(w, int):
+            assert isinstance(g, int) and g == 0, f"conf {c}"
+        else:
+            assert_bit_equal(g.cpu().numpy(), w, f"conf {c:.3f}")
+    # and the separate calls of the reference's loop give the same rows
+    for c in (confs[0], confs[11], confs[-2]):
+        p = dict(params)
+        p["confidence"] = float(c)
+        one = filter_results(pred, p)
+        idx = confs.index(c)
+        if isinstance(one, int):
+            assert isinstance(got[idx], int)
+        else:
+            assert torch.equal(one, got[idx])
+    assert params["confidence"] == 0.5, "params were modified"
+    det = detections_by_conf(pred, params, confs[:3])
+    assert len(det) == 3 and len(det[0]) == B and len(det[0][0]) == C
+    rows0 = want[0]
+    for b in range(B):
+        for c in range(C):
+            ref = rows0[(rows0[:, 0] == b) & (rows0[:, 7] == c)][:, 1:6]
+            got_bc = det[0][b][c]
+            assert got_bc.shape[0] == ref.shape[0]
+            if ref.shape[0]:
+                assert np.all(np.diff(got_bc[:, 4]) >= 0)
+                assert_bit_equal(np.sort(got_bc, axis=0), np.sort(ref, axis=0), f"image {b} class {c}")

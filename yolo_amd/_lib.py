@@ -72,6 +72,8 @@ SYMBOLS = {
     "yolo_amd_filter_img_class": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                   ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "yolo_amd_rescale_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                               ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "yolo_amd_conv_cout_pad": (ctypes.c_int, [ctypes.c_int]),
     "yolo_amd_conv_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p]),
