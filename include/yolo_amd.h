@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YOLO_AMD_ABI_VERSION 2
+#define YOLO_AMD_ABI_VERSION 3
 #define YOLO_AMD_MAX_HEADS 4
 #define YOLO_AMD_MAX_ANCHORS 8
 
@@ -144,6 +144,9 @@ typedef struct {
     const yolo_amd_head_desc* decode;
     int decode_rows;      /* N_total of the prediction tensor                   */
     int decode_anchors;   /* A                                                  */
+    int fuse_next;        /* first layer only: run it together with the next    */
+                          /* descriptor (3x3 stride-2, 32 -> 64 channels) as one */
+                          /* launch; this layer's dst is then not written        */
 } yolo_amd_conv_desc;
 
 /* Output channels are padded to a whole channel tile: returns the padded

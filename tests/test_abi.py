@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} is declared in yolo_amd.h but not exported"
         assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype in yolo_amd/_lib.py"
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.yolo_amd_abi_version() == 2
+    assert _lib.lib.yolo_amd_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header():
@@ -40,7 +40,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(yolo_amd_head_desc), offsetof(yolo_amd_head_desc, stride),
          offsetof(yolo_amd_head_desc, anchor_h), sizeof(yolo_amd_conv_desc),
          offsetof(yolo_amd_conv_desc, c0), offsetof(yolo_amd_conv_desc, first_layer),
-         offsetof(yolo_amd_conv_desc, decode), offsetof(yolo_amd_conv_desc, decode_anchors));
+         offsetof(yolo_amd_conv_desc, decode), offsetof(yolo_amd_conv_desc, fuse_next));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as tmp:
@@ -51,7 +51,7 @@ int main(void) {
         got = [int(v) for v in subprocess.check_output([exe]).split()]
     H, C = _lib.HeadDesc, _lib.ConvDesc
     want = [ctypes.sizeof(H), H.stride.offset, H.anchor_h.offset, ctypes.sizeof(C), C.c0.offset,
-            C.first_layer.offset, C.decode.offset, C.decode_anchors.offset]
+            C.first_layer.offset, C.decode.offset, C.fuse_next.offset]
     assert got == want
 
 

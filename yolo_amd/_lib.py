@@ -50,6 +50,7 @@ class ConvDesc(ctypes.Structure):
         ("decode", ctypes.POINTER(HeadDesc)),
         ("decode_rows", ctypes.c_int),
         ("decode_anchors", ctypes.c_int),
+        ("fuse_next", ctypes.c_int),
     ]
 
 
@@ -97,7 +98,7 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    want = 2
+    want = 3
     got = lib.yolo_amd_abi_version()
     if got != want:
         raise ImportError(f"{LIB_PATH} has ABI version {got}, the Python side expects {want}")

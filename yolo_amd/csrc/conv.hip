@@ -973,6 +973,226 @@ conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
     }
 }
 
+// ---------------------------------------------------------------- fused stem
+// The first layer writes 64 bytes per pixel of the full-resolution image
+// (354 MB at batch 32 x 416^2) only for the stride-2 layer behind it to read
+// them back: both are bound by that round trip.  This kernel computes the two
+// layers together.  A workgroup takes 8x16-pixel tiles of the SECOND layer's
+// output; per tile it
+//   A. stages the 19x35 input patch (fp32, every channel) in LDS, as
+//      conv_first_kernel does (range-checked loads, next tile prefetched);
+//   B. computes the 17x33 first-layer pixels the tile needs, 16 at a time, with
+//      exactly conv_first_kernel's MFMA sequence (so the values are the same
+//      bits), and parks them as bf16 in LDS, zero where the second layer pads;
+//      layout [8-channel chunk q][row][column parity][column/2] x 16 B, so the
+//      stride-2 reads of phase C are 16 consecutive slots;
+//   C. runs the second layer's nine taps from that patch: wave = 4 output rows x
+//      32 channels, its weight fragments (9 taps x 2) live in registers for the
+//      whole kernel, K-steps in the im2col kernel's order (same accumulators);
+//   D. bias + LeakyReLU + one rounding, output tile through LDS, 16-byte stores.
+// First-layer activations are never written to memory.
+constexpr int STEM_TY = 8, STEM_TX = 16;                   // second-layer output tile
+constexpr int STEM_PR = 2 * STEM_TY + 1, STEM_PC = 2 * STEM_TX + 1;      // 17 x 33 first-layer pixels
+constexpr int STEM_IR = STEM_PR + 2, STEM_IC = STEM_PC + 2;              // 19 x 35 input pixels
+constexpr int STEM_NPIX = STEM_PR * STEM_PC;               // 561
+constexpr int STEM_STRIPS = (STEM_NPIX + 15) / 16;         // 36
+constexpr int STEM_HALF = STEM_TX + 1;                     // 17 columns per parity
+constexpr int STEM_IN_BYTES = 8192;                        // >= 3 * 19 * 35 * 4
+constexpr int STEM_L0_BYTES = 4 * STEM_PR * 2 * STEM_HALF * 16;          // 36992
+
+struct StemArgs {
+    const float* src;
+    const float* w0;
+    const float* b0;
+    const __bf16* w1;      // [9][64][32] bf16 (K-tile major)
+    const float* b1;
+    __bf16* dst;
+    int B, Cin, H, W, Ho, Wo;
+    float slope0;
+    int leaky1;
+    uint32_t src_bytes;
+    int tiles_x, tiles_y;
+};
+
+__global__ void __launch_bounds__(256)
+conv_stem_kernel(const StemArgs a) {
+    constexpr int PLANE_IN = STEM_IR * STEM_IC;
+    __shared__ __attribute__((aligned(1024))) char lds[STEM_IN_BYTES + STEM_L0_BYTES];
+    float* const inpatch = reinterpret_cast<float*>(lds);
+    char* const l0 = lds + STEM_IN_BYTES;                  // first-layer patch; later the output tile
+    static_assert(STEM_TY * STEM_TX * 64 * 2 <= STEM_L0_BYTES, "output tile fits where the patch was");
+    static_assert(STEM_STRIPS % 4 == 0, "strips split evenly over the four waves");
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int K0 = 9 * a.Cin;
+
+    // ---- first layer: im2col offsets inside the input patch, weights (hi/lo), bias
+    int offl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * q + j;
+        offl[j] = 0;
+        if (k < K0) {
+            const int tap = k / a.Cin, c = k - tap * a.Cin;
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            offl[j] = (c * STEM_IR + kh) * STEM_IC + kw;
+        }
+    }
+    bf16x8 wf[2], wl[2];
+    f32x4 bv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ch = 8 * (n >> 2) + 4 * i + (n & 3);     // MFMA i, row r <-> channel 8*(r>>2) + 4*i + (r&3)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * q + j;
+            const float wv = k < K0 ? a.w0[k * 32 + ch] : 0.f;
+            wf[i][j] = (__bf16)wv;
+            wl[i][j] = (__bf16)(wv - (float)wf[i][j]);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[i][t] = a.b0[8 * q + 4 * i + t];
+    }
+    // ---- second layer: this wave's weight fragments, all nine taps
+    const int wpx = w & 1, wch = w >> 1;                   // pixel half (4 rows), channel half (32)
+    bf16x8 w1f[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+            w1f[tap][tc] = *reinterpret_cast<const bf16x8*>(a.w1 + ((tap * 64 + wch * 32 + tc * 16 + n) * 32 + q * 8));
+
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.src, 0, (int)a.src_bytes, (int)kRawBufferFlags);
+
+    // ---- input patch staging: the elements this thread loads, the same for every tile
+    const int total = a.Cin * PLANE_IN;
+    int pre[8], prc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int e = min((int)threadIdx.x + 256 * u, total - 1);
+        const int c = e / PLANE_IN, r2 = e - c * PLANE_IN;
+        const int r = r2 / STEM_IC, col = r2 - r * STEM_IC;
+        pre[u] = (c * a.H + r) * a.W + col;
+        prc[u] = (r << 16) | col;
+    }
+    const int per_image = a.tiles_x * a.tiles_y, ntiles = per_image * a.B;
+    uint32_t stage[8];
+    auto fetch = [&](int tile) {
+        const int b = tile / per_image, t2 = tile - b * per_image;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int x0 = 2 * tx * STEM_TX - 2, y0 = 2 * ty * STEM_TY - 2;
+        const int origin = (b * a.Cin * a.H + y0) * a.W + x0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int gy = y0 + (prc[u] >> 16), gx = x0 + (prc[u] & 0xffff);
+            const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const uint32_t o = ok ? (uint32_t)((origin + pre[u]) * 4) : 0x80000000u;
+            stage[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x >= ntiles) return;
+    const int step = gridDim.x, last = ntiles - 1;
+    fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += step) {
+        const int b = tile / per_image, t2 = tile - b * per_image;
+        const int tyi = t2 / a.tiles_x, txi = t2 - tyi * a.tiles_x;
+        const int oy0 = tyi * STEM_TY, ox0 = txi * STEM_TX;
+        __syncthreads();                                   // the previous tile's output tile has been stored
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if ((int)threadIdx.x + 256 * u < total) inpatch[threadIdx.x + 256 * u] = __uint_as_float(stage[u]);
+        __syncthreads();
+        fetch(min(tile + step, last));                     // next tile streams in meanwhile
+
+        // ---- B: first-layer pixels of the patch, 16 per strip
+#pragma unroll 1
+        for (int i = 0; i < STEM_STRIPS / 4; ++i) {
+            const int p = (w + 4 * i) * 16 + n;
+            const int pp = min(p, STEM_NPIX - 1);
+            const int pr = pp / STEM_PC, pc = pp - pr * STEM_PC;
+            const float* ip = inpatch + pr * STEM_IC + pc;
+            bf16x8 xf, xl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = ip[offl[j]];
+                xf[j] = (__bf16)t;
+                xl[j] = (__bf16)(t - (float)xf[j]);
+            }
+            f32x4 acc0[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[m], xf, bv[m], 0, 0, 0);
+                acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xl, acc0[m], 0, 0, 0);
+                acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf, acc0[m], 0, 0, 0);
+            }
+            const int y = 2 * oy0 - 1 + pr, x = 2 * ox0 - 1 + pc;
+            const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            bf16x8 pk;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    pk[4 * m + t] = inside ? (__bf16)leaky_max(acc0[m][t], a.slope0) : (__bf16)0.f;
+            if (p < STEM_NPIX)
+                *reinterpret_cast<bf16x8*>(l0 + (((q * STEM_PR + pr) * 2 + (pc & 1)) * STEM_HALF + (pc >> 1)) * 16) = pk;
+        }
+        __syncthreads();
+
+        // ---- C: second layer, nine taps, K-steps in tap order
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            bf16x8 xf[4];
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                const int pr = 2 * (wpx * 4 + tp) + kh;
+                xf[tp] = *reinterpret_cast<const bf16x8*>(
+                    l0 + (((q * STEM_PR + pr) * 2 + (kw & 1)) * STEM_HALF + n + (kw >> 1)) * 16);
+            }
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp)
+                    acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[tap][tc], xf[tp], acc[tc][tp], 0, 0, 0);
+        }
+        __syncthreads();                                   // everyone is done reading the patch
+
+        // ---- D: output tile (128 pixels x 64 channels) through LDS
+        const int cq = q * 4;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const int slot = (wpx * 4 + tp) * STEM_TX + n;
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                const int chl = wch * 32 + tc * 16 + cq;
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(a.b1 + chl);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float xx = acc[tc][tp][r] + bs[r];
+                    if (a.leaky1) xx = xx > 0.f ? xx : 0.1f * xx;
+                    v[r] = xx;
+                }
+                tile_put<64>(l0, slot, chl, v, false);
+            }
+        }
+        __syncthreads();
+        auto pix = [&](int slot) -> long long {
+            const int y = oy0 + slot / STEM_TX, x = ox0 + slot % STEM_TX;
+            return (y < a.Ho && x < a.Wo) ? ((long long)b * a.Ho + y) * a.Wo + x : -1;
+        };
+        tile_store<STEM_TY * STEM_TX, 64, 256>(l0, a.dst, 64, 0, pix);
+    }
+}
+
 // ---------------------------------------------------------------- launch
 static int pick_bk(int c0, int c1) { return (c0 % 64 == 0 && c1 % 64 == 0) ? 64 : 32; }
 static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
@@ -1145,12 +1365,46 @@ extern "C" int yolo_amd_conv_cout_pad(int cout) {
     return (cout + bn - 1) / bn * bn;
 }
 
+// descs[0] (first layer, fuse_next set) and descs[1] as one launch
+static int launch_stem(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc& d1, hipStream_t stream) {
+    YA_REQUIRE(d0.first_layer && d0.ksize == 3 && d0.stride == 1 && d0.c0 >= 1 && d0.c0 <= 3 && d0.c1 == 0 &&
+                   d0.cout == 32 && !d0.residual && !d0.dst_fp32 && d0.up0 == 0,
+               "conv: the fused stem needs a 3x3 stride-1 first layer with <= 3 input and 32 output channels");
+    YA_REQUIRE(!d1.first_layer && d1.ksize == 3 && d1.stride == 2 && d1.c0 == 32 && d1.c1 == 0 && d1.cout == 64 &&
+                   d1.cout_pad == 64 && !d1.residual && !d1.dst_fp32 && d1.up0 == 0 && d1.B == d0.B &&
+                   d1.H == d0.H && d1.W == d0.W && d1.k_pad == 288 && !d1.decode,
+               "conv: the fused stem needs a 3x3 stride-2 32 -> 64 layer on the first layer's output");
+    YA_REQUIRE(d0.src0 && d0.weight && d0.bias && d1.weight && d1.bias && d1.dst, "conv: null pointer");
+    const long long src_bytes = (long long)d0.B * d0.c0 * d0.H * d0.W * 4;
+    YA_REQUIRE(src_bytes < (1ll << 31), "conv: first layer input must be smaller than 2 GiB");
+    StemArgs a;
+    a.src = (const float*)d0.src0; a.w0 = (const float*)d0.weight; a.b0 = d0.bias;
+    a.w1 = (const __bf16*)d1.weight; a.b1 = d1.bias; a.dst = (__bf16*)d1.dst;
+    a.B = d0.B; a.Cin = d0.c0; a.H = d0.H; a.W = d0.W;
+    a.Ho = (d0.H + 2 - 3) / 2 + 1; a.Wo = (d0.W + 2 - 3) / 2 + 1;
+    YA_REQUIRE((long long)a.B * a.Ho * a.Wo * 64 < (1ll << 31), "conv: stem output too large");
+    a.slope0 = d0.leaky ? 0.1f : 1.0f; a.leaky1 = d1.leaky;
+    a.src_bytes = (uint32_t)src_bytes;
+    a.tiles_x = (a.Wo + STEM_TX - 1) / STEM_TX; a.tiles_y = (a.Ho + STEM_TY - 1) / STEM_TY;
+    const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.B;
+    dim3 grid((unsigned)std::min<long long>(ntiles, 256 * 2));
+    hipLaunchKernelGGL(conv_stem_kernel, grid, dim3(256), 0, stream, a);
+    return YA_OK;
+}
+
 extern "C" int yolo_amd_conv_forward(const yolo_amd_conv_desc* descs, int n, const void* zero_page,
                                      void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     YA_REQUIRE(descs && n >= 0, "conv_forward: null descriptor array");
     for (int i = 0; i < n; ++i) {
-        int rc = launch_conv(descs[i], zero_page, stream);
+        int rc;
+        if (descs[i].first_layer && descs[i].fuse_next) {
+            YA_REQUIRE(i + 1 < n, "conv_forward: fuse_next on the last descriptor");
+            rc = launch_stem(descs[i], descs[i + 1], stream);
+            ++i;
+        } else {
+            rc = launch_conv(descs[i], zero_page, stream);
+        }
         if (rc != YA_OK) return rc;
     }
     YA_CHECK_HIP(hipGetLastError());

@@ -19,6 +19,7 @@ Nothing here computes on the CPU; host code only builds descriptors.
 from __future__ import annotations
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -261,6 +262,21 @@ class Plan:
             d.leaky = int(ent["leaky"])
             d.dst_fp32 = int(op["fp32"])
             d.first_layer = int(op["first"])
+        # The first layer and the stride-2 layer behind it run as one launch when
+        # nothing else reads the first layer's output (its 64 bytes per input
+        # pixel then never go to memory).  Plans that keep every layer readable
+        # run them separately; YOLO_AMD_STEM=0 does too (development knob).
+        self.fused_stem = False
+        if (not self.keep_all and len(ops) >= 2 and os.environ.get("YOLO_AMD_STEM", "1") != "0"):
+            o0, o1 = ops[0], ops[1]
+            e0, e1 = o0["ent"], o1["ent"]
+            readers = [op for op in ops if any(s_[0] == f"L{o0['index']}" for s_ in op["src"])
+                       or op["res"] == f"L{o0['index']}"]
+            if (o0["first"] and e0["k"] == 3 and e0["stride"] == 1 and e0["cout"] == 32 and e0["cin"] <= 3
+                    and readers == [o1] and o1["src"] == [(f"L{o0['index']}", 32, 0)] and not o1["res"]
+                    and e1["k"] == 3 and e1["stride"] == 2 and e1["cout"] == 64 and not o1["fp32"]):
+                self.descs[0].fuse_next = 1
+                self.fused_stem = True
         self.refold()
 
         # ---- decode descriptors
