@@ -195,7 +195,7 @@ def main():
             with open(tpath) as fh:
                 traffic = round(json.load(fh)["hbm_bytes_per_launch"])
             traffic_src = "profiles/round1_conv_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per conv launch)"
-        n_convs = len(plan.ops)
+        n_convs = len(plan.ops) - (1 if getattr(plan, "fused_stem", False) else 0)
         N = plan.N
         result = {
             "metric": "images/sec (node) YOLOv3-416 end-to-end incl. NMS",

@@ -10,10 +10,14 @@ def main(path, B=32, H=416):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     names = [r['Kernel_Name'] for r in rows]
-    idx = [i for i, n in enumerate(names) if 'conv_first' in n][-1]
+    fused = any('conv_stem' in n for n in names)
+    idx = [i for i, n in enumerate(names) if ('conv_stem' in n if fused else 'conv_first' in n)][-1]
     table = engine.graph_from_blocks(orc.parse_cfg_text(yolov3_cfg_text()), 3, 80, 3)
     ops, heads, info = engine.build_ops(table, B, H, 3)
-    convs = [r for r in rows[idx:] if 'conv' in r['Kernel_Name']][:75]
+    if fused:                      # first two layers are one launch
+        merged = dict(ops[1]); merged['stem'] = ops[0]
+        ops = [merged] + ops[2:]
+    convs = [r for r in rows[idx:] if 'conv' in r['Kernel_Name']][:len(ops)]
     tot = 0; groups = {}
     prev_end = None; gaps = 0
     for op, r in zip(ops, convs):
@@ -22,6 +26,9 @@ def main(path, B=32, H=416):
         if prev_end: gaps += (int(r['Start_Timestamp']) - prev_end) / 1e3
         prev_end = int(r['End_Timestamp'])
         fl = 2 * B * op['Ho'] * op['Wo'] * e['cout'] * e['cin'] * e['k'] ** 2
+        if 'stem' in op:
+            o0 = op['stem']; e0 = o0['ent']
+            fl += 2 * B * o0['Ho'] * o0['Wo'] * e0['cout'] * e0['cin'] * e0['k'] ** 2
         key = (e['k'], e['stride'], e['cin'], e['cout'], op['Ho'])
         g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += dur; g[2] += fl
         tot += dur
