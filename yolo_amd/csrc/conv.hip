@@ -606,13 +606,25 @@ struct Conv3Args {
     int tiles_n;                       // channel tiles
 };
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+// WAVES = 4: wave cg owns all 11 pixel groups (three workgroups per CU).
+// WAVES = 8: waves cg and cg + 4 split them 6 + 5, 48 accumulator registers each,
+// so that two workgroups per CU still give four waves per SIMD -- for the maps
+// whose 13x13 tiles number no more than two per CU.
+template <int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 3 : 4, WAVES == 4 ? 3 : 4)))
 conv3x3_patch_kernel(const Conv3Args a) {
+    constexpr int NH = WAVES / 4;                  // waves per channel group
+    constexpr int NTP = NH == 1 ? P3_TP : 6;       // pixel groups per wave (upper bound)
+    constexpr int PP = 16 / WAVES;                 // patch LDS-DMA instructions per wave per chunk
+    constexpr int WP = 8 / WAVES;                  // weight LDS-DMA instructions per wave per stage
     __shared__ __attribute__((aligned(1024))) char lds[2 * P3_PATCH + 2 * P3_WSTAGE];
     char* const wring = lds + 2 * P3_PATCH;
 
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // = channel group and patch plane
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cg = w & 3, half = w >> 2;           // channel group (= patch plane), pixel-group half
+    const int tp0 = half * 6;                      // first pixel group of this wave
+    const int ntp = NH == 1 ? P3_TP : (half == 0 ? 6 : P3_TP - 6);
 
     int tile;
     {
@@ -629,53 +641,60 @@ conv3x3_patch_kernel(const Conv3Args a) {
     const int ox0 = ((gt - cb * per_img) % a.tiles_x) * P3_TS;
 
     const int r = lane & 15, q = lane >> 4;
-    int tyb[P3_TP];                            // byte offset of (plane q, patch row ty) per pixel group
+    int tyb[NTP];                              // byte offset of (plane q, patch row ty) per pixel group
 #pragma unroll
-    for (int tp = 0; tp < P3_TP; ++tp) {
-        const int p = min(tp * 16 + r, P3_NPIX - 1);
+    for (int tp = 0; tp < NTP; ++tp) {
+        const int p = min((tp0 + tp) * 16 + r, P3_NPIX - 1);
         tyb[tp] = q * P3_PLANE + (p / P3_TS) * 256;
     }
-    const int wfrag = (w * 32) * 64 + slot_of<32>(r, q) * 16;
+    const int wfrag = (cg * 32) * 64 + slot_of<32>(r, q) * 16;
 
-    // ---- patch fill: instruction i of this wave = rows 4i..4i+3 of plane w
-    int poff[4];
+    // ---- patch fill: 16 LDS-DMA instructions of 4 rows each; this wave's are
+    // rows 4i..4i+3 of plane cg for i = half*PP .. half*PP + PP - 1
+    int poff[PP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int py = 4 * i + q, slot = r;
+    for (int ii = 0; ii < PP; ++ii) {
+        const int py = 4 * (half * PP + ii) + q, slot = r;
         const int px = (slot - P3_TS * py) & 15;
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        poff[i] = (py < P3_TS + 2 && px < P3_TS + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                      ? ((cb * a.H + iy) * a.W + ix) * a.C + w * 8
-                      : -1;
+        poff[ii] = (py < P3_TS + 2 && px < P3_TS + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                       ? ((cb * a.H + iy) * a.W + ix) * a.C + cg * 8
+                       : -1;
     }
-    // ---- weight fill: two LDS-DMA instructions per wave per (chunk, tap) stage
+    auto issue_patch = [&](int chunk, int ii) {            // ii: wave-uniform
+        // (selected with compares: a run-time index would move the array out of registers)
+        int po;
+        if constexpr (PP == 4) po = ii == 0 ? poff[0] : ii == 1 ? poff[1] : ii == 2 ? poff[2] : poff[3];
+        else po = ii == 0 ? poff[0] : poff[1];
+        const __bf16* pp = po >= 0 ? a.src + (po + chunk * 32) : a.zero;
+        lds_dma16(pp, lds + (chunk & 1) * P3_PATCH + cg * P3_PLANE + (half * PP + ii) * 1024);
+    };
+    // ---- weight fill: 8 LDS-DMA instructions per (chunk, tap) stage, WP per wave
     const int cout_pad = a.tiles_n * 128;
-    int woff[2];
+    int woff[WP];
     {
         const int qw = (lane & 3) ^ chunk_swizzle<32>(lane >> 2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) woff[i] = (n0 + (w * 2 + i) * 16 + (lane >> 2)) * 32 + qw * 8;
+        for (int i = 0; i < WP; ++i) woff[i] = (n0 + (w * WP + i) * 16 + (lane >> 2)) * 32 + qw * 8;
     }
     const int wstep_tap = (a.C / 32) * cout_pad * 32;     // [K/32][cout_pad][32]: one tap further
     const int wstep_chunk = cout_pad * 32;
     auto issue_w = [&](int chunk, int tap, int buf) {
         const int delta = tap * wstep_tap + chunk * wstep_chunk;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) lds_dma16(a.wgt + (woff[i] + delta), wring + buf * P3_WSTAGE + (w * 2 + i) * 1024);
+        for (int i = 0; i < WP; ++i)
+            lds_dma16(a.wgt + (woff[i] + delta), wring + buf * P3_WSTAGE + (w * WP + i) * 1024);
     };
 
-    f32x4 acc[2][P3_TP];
+    f32x4 acc[2][NTP];
 #pragma unroll
     for (int tc = 0; tc < 2; ++tc)
 #pragma unroll
-        for (int tp = 0; tp < P3_TP; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tp = 0; tp < NTP; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int NCH = a.C / 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const __bf16* p = poff[i] >= 0 ? a.src + poff[i] : a.zero;
-        lds_dma16(p, lds + w * P3_PLANE + i * 1024);
-    }
+    for (int ii = 0; ii < PP; ++ii) issue_patch(0, ii);
     issue_w(0, 0, 0);
     bool patch_behind = false;                 // a patch load was issued after the weights now awaited
     int buf = 0;
@@ -693,13 +712,8 @@ conv3x3_patch_kernel(const Conv3Args a) {
             // instruction of the next chunk's patch
             if (tap < 8) issue_w(chunk, tap + 1, buf ^ 1);
             else if (more_chunks) issue_w(chunk + 1, 0, buf ^ 1);
-            patch_behind = tap < 4 && more_chunks;
-            if (patch_behind) {
-                // (instruction `tap` of the four; written out because the loop is not unrolled)
-                const int po = tap == 0 ? poff[0] : tap == 1 ? poff[1] : tap == 2 ? poff[2] : poff[3];
-                const __bf16* pp = po >= 0 ? a.src + (po + (chunk + 1) * 32) : a.zero;
-                lds_dma16(pp, lds + ((chunk + 1) & 1) * P3_PATCH + w * P3_PLANE + tap * 1024);
-            }
+            patch_behind = tap < PP && more_chunks;
+            if (patch_behind) issue_patch(chunk + 1, tap);
 
             const int colb = ((r + kw + P3_TS * kh) & 15) * 16 + kh * 256;
             const char* ws = wring + buf * P3_WSTAGE + wfrag;
@@ -711,13 +725,15 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
 #pragma unroll
-                for (int tp = 0; tp < 6; ++tp)
+                for (int tp = 0; tp < 6; ++tp) {
+                    if (NH == 2 && tp == 5 && ntp == 5) break;          // the second half has five groups
 #pragma unroll
                     for (int tc = 0; tc < 2; ++tc)
                         acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
-            {
+            if constexpr (NH == 1) {
+                __builtin_amdgcn_sched_barrier(0);
                 bf16x8 xf[5];
 #pragma unroll
                 for (int tp = 0; tp < 5; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[6 + tp] + colb);
@@ -744,15 +760,16 @@ conv3x3_patch_kernel(const Conv3Args a) {
         };
         __syncthreads();
         if (a.res) {
-            tile_load_residual<NSLOT, 128, 256>(lds, a.res, a.zero, a.Cout, n0, w, lane, pix);
+            tile_load_residual<NSLOT, 128, 64 * WAVES>(lds, a.res, a.zero, a.Cout, n0, w, lane, pix);
             __syncthreads();
         }
 #pragma unroll
-        for (int tp = 0; tp < P3_TP; ++tp) {
-            const int slot = tp * 16 + r;
+        for (int tp = 0; tp < NTP; ++tp) {
+            if (tp >= ntp) break;
+            const int slot = (tp0 + tp) * 16 + r;
 #pragma unroll
             for (int tc = 0; tc < 2; ++tc) {
-                const int chl = w * 32 + tc * 16 + cq;
+                const int chl = cg * 32 + tc * 16 + cq;
                 const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + chl);
                 float v[4];
 #pragma unroll
@@ -765,18 +782,18 @@ conv3x3_patch_kernel(const Conv3Args a) {
             }
         }
         __syncthreads();
-        tile_store<NSLOT, 128, 256>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
+        tile_store<NSLOT, 128, 64 * WAVES>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
         return;
     }
 #pragma unroll
-    for (int tp = 0; tp < P3_TP; ++tp) {
-        const int p = tp * 16 + r;
-        if (p >= P3_NPIX) continue;
+    for (int tp = 0; tp < NTP; ++tp) {
+        const int p = (tp0 + tp) * 16 + r;
+        if (tp >= ntp || p >= P3_NPIX) continue;
         const int ty = p / P3_TS, tx = p - ty * P3_TS;
         const size_t m = ((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
 #pragma unroll
         for (int tc = 0; tc < 2; ++tc) {
-            const int ch = n0 + w * 32 + tc * 16 + cq;
+            const int ch = n0 + cg * 32 + tc * 16 + cq;
             if (ch >= a.Cout) continue;
             const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + ch);
             const size_t o = m * a.Cout + ch;
@@ -1273,21 +1290,26 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     YA_REQUIRE((long long)d.B * d.H * d.W * (d.c0 + d.c1) < (1ll << 31) && (long long)d.cout_pad * K < (1ll << 31),
                "conv: tensor too large for 32-bit element offsets");
     // Stride-1 3x3 layers on 13*2^n feature maps can take the patch-reuse kernel.
-    // It wins where its 13x13-pixel tiles give at least ~4 workgroups per CU
-    // (measured: 104x104 and 52x52 maps at batch 32); on smaller maps the 128-
-    // pixel tiles of the im2col kernel fill the GPU better.  YOLO_AMD_CONV3=0/1
-    // forces the choice (development knob).
+    // Measured at batch 32 (tools/conv_bench.py): with two to six 13x13 tiles per
+    // CU (52x52 and 26x26 maps) its eight-wave form wins, with more (104x104) the
+    // four-wave form, with one tile per CU (13x13 maps) the 128-pixel tiles of the
+    // im2col kernel fill the GPU as well.  YOLO_AMD_CONV3=0/1 and
+    // YOLO_AMD_CONV3_WAVES=4/8 force the choice (development knobs).
     const long long p3_groups = (long long)d.B * (d.H / P3_TS) * (d.W / P3_TS) * (d.cout_pad / 128);
     const int p3 = env_int("YOLO_AMD_CONV3", -1);
     if (d.ksize == 3 && d.stride == 1 && d.c1 == 0 && d.up0 == 0 && d.H % P3_TS == 0 && d.W % P3_TS == 0 &&
-        d.cout_pad % 128 == 0 && (p3 == 1 || (p3 < 0 && p3_groups >= 1000))) {
+        d.cout_pad % 128 == 0 && (p3 == 1 || (p3 < 0 && p3_groups >= 500))) {
         Conv3Args p;
         p.src = (const __bf16*)d.src0; p.wgt = (const __bf16*)d.weight; p.bias = d.bias;
         p.res = (const __bf16*)d.residual; p.dst = d.dst; p.zero = (const __bf16*)zero_page;
         p.C = d.c0; p.H = d.H; p.W = d.W; p.Cout = d.cout; p.K = K; p.leaky = d.leaky; p.dst_fp32 = d.dst_fp32;
         p.tiles_y = d.H / P3_TS; p.tiles_x = d.W / P3_TS; p.ntiles = d.B * p.tiles_y * p.tiles_x;
         p.tiles_n = d.cout_pad / 128;
-        hipLaunchKernelGGL(conv3x3_patch_kernel, dim3(p.ntiles * p.tiles_n), dim3(256), 0, stream, p);
+        const int p3w = env_int("YOLO_AMD_CONV3_WAVES", p3_groups <= 1536 ? 8 : 4);
+        if (p3w == 8)
+            hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else
+            hipLaunchKernelGGL(conv3x3_patch_kernel<4>, dim3(p.ntiles * p.tiles_n), dim3(256), 0, stream, p);
         return YA_OK;
     }
     ConvArgs a;
