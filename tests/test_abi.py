@@ -58,11 +58,12 @@ int main(void) {
 def test_host_side_argument_checks_need_no_gpu():
     from yolo_amd._lib import lib
     assert lib.yolo_amd_filter_results_workspace_bytes(0, 10, 80) == 0
-    # per image: keys, boxes, scores, kept positions (32 B per box) plus the
-    # suppression-matrix tiles (N*N/128 + 2N + 64*min(N, C) words of 8 bytes)
+    # per image: keys, boxes, scores, kept positions (32 B per box), eight candidate
+    # lists of N keys, plus the suppression-matrix tiles
+    # (N*N/128 + 2N + 64*min(N, C) words of 8 bytes)
     N = 10647
     nbytes = lib.yolo_amd_filter_results_workspace_bytes(32, N, 80)
-    per_image = N * 32 + (N * N // 128 + 2 * N + 64 * 80) * 8
+    per_image = N * 32 + 8 * N * 8 + (N * N // 128 + 2 * N + 64 * 80) * 8
     assert 32 * per_image <= nbytes < 32 * per_image * 1.02 + (1 << 16)
     assert lib.yolo_amd_filter_results_workspace_bytes(1, 22743, 80) > 32768 * 8   # keys padded to 32768
     assert lib.yolo_amd_conv_cout_pad(255) == 256 and lib.yolo_amd_conv_cout_pad(32) == 32

@@ -27,7 +27,10 @@ def hip_filter(pred_np, conf, nms, C, device="cuda"):
 def test_library_is_the_hip_one():
     from yolo_amd import _lib
     assert torch.cuda.is_available()
-    assert _lib.lib.yolo_amd_abi_version() == 1
+    import os, re
+    from helpers import ROOT
+    header = open(os.path.join(ROOT, "include", "yolo_amd.h")).read()
+    assert _lib.lib.yolo_amd_abi_version() == int(re.search(r"#define YOLO_AMD_ABI_VERSION\s+(\d+)", header).group(1))
 
 
 @pytest.mark.parametrize("name", [n for n in NMS_CASES if not n.startswith("full")])

@@ -5,9 +5,11 @@
 //   compact  : stream the (B,N,D) tensor once through LDS; for every row with
 //              objectness > conf compute corners, first-index class argmax and
 //              a 64-bit sort key; wave-ballot compaction into per-image lists
-//   sort     : one workgroup per image, LDS bitonic sort of the keys
-//              (class asc, objectness desc, original row asc) and segment
-//              boundaries per (image, class)
+//   sort     : candidates are compacted into eight lists per image by class
+//              range; one workgroup per list, LDS bitonic sort of the keys
+//              (class asc, objectness desc, original row asc), written at the
+//              list's place in the image's key array, and segment boundaries
+//              per (image, class); a small plan kernel lays out the tiles
 //   mask     : 64x64 tiles of the per-segment suppression matrix, one wave per
 //              tile, spread over the whole GPU, stored tile by tile: bit j of
 //              word i of tile (t, w) says box 64w+j (later in the visiting
@@ -134,8 +136,8 @@ constexpr int CNT_STRIDE = 32;
 template <int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 nms_compact_kernel(const float* __restrict__ pred, int N, int D, int C, float conf,
-                   int key_stride, int slice_bytes, int* __restrict__ cand_count,
-                   unsigned long long* __restrict__ keys, float4* __restrict__ boxes,
+                   int raw_stride, int G, int slice_bytes, int* __restrict__ cand_count,
+                   unsigned long long* __restrict__ raw_keys, float4* __restrict__ boxes,
                    float* __restrict__ scores) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -171,26 +173,38 @@ nms_compact_kernel(const float* __restrict__ pred, int N, int D, int C, float co
         obj = r[4];
         pass = (obj > conf) && (obj > 0.0f);
     }
-    unsigned long long m = __ballot(pass);
-    if (m == 0) return;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&cand_count[b * CNT_STRIDE], __popcll(m));
-    base = __shfl(base, 0);
+    if (__ballot(pass) == 0) return;
+    int bi = 0;
+    float best = 0.f;
     if (pass) {
         // first-index maximum; a NaN beats every number and the first NaN wins
-        float best = r[5];
-        int bi = 0;
+        best = r[5];
 #pragma unroll 8
         for (int j = 1; j < C; ++j) {
             float v = r[5 + j];
             if ((v > best) || ((v != v) && !(best != best))) { best = v; bi = j; }
         }
+    }
+    // Candidates go to one of G lists per image by class range (list g holds
+    // the classes c with c*G/C == g), so that G workgroups can sort an image.
+    const int grp = (int)(((long long)bi * G) / C);
+    for (int g = 0; g < G; ++g) {
+        const unsigned long long m = __ballot(pass && grp == g);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cand_count[(b * G + g) * CNT_STRIDE], __popcll(m));
+        base = __shfl(base, 0);
+        if (pass && grp == g) {
+            const int row = row0 + lane;
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            raw_keys[((size_t)b * G + g) * raw_stride + slot] = make_key(bi, obj, row);
+        }
+    }
+    if (pass) {
         float cx = r[0], cy = r[1], w = r[2], h = r[3];
         float hw = __fdiv_rn(w, 2.0f), hh = __fdiv_rn(h, 2.0f);
         float4 bx = make_float4(__fsub_rn(cx, hw), __fsub_rn(cy, hh), __fadd_rn(cx, hw), __fadd_rn(cy, hh));
         const int row = row0 + lane;
-        const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-        keys[(size_t)b * key_stride + slot] = make_key(bi, obj, row);
         boxes[(size_t)b * N + row] = bx;
         scores[(size_t)b * N + row] = best;
     }
@@ -216,56 +230,68 @@ __device__ __forceinline__ void bitonic_sort(Ptr s, int P) {
     }
 }
 
+// One workgroup per (class group, image): sorts the group's candidate list and
+// writes it at its place in the image's sorted key array (the groups hold
+// ascending class ranges, so group g starts where the groups before it end),
+// and records where each of its classes starts and ends.
 __global__ void __launch_bounds__(SORT_THREADS)
-nms_sort_kernel(const int* __restrict__ cand_count, int key_stride, int C,
+nms_sort_kernel(const int* __restrict__ cand_count, int G, int raw_stride,
+                unsigned long long* __restrict__ raw_keys, int key_stride, int C,
                 unsigned long long* __restrict__ keys, int* __restrict__ seg_start,
-                int* __restrict__ seg_end, int* __restrict__ tile_base, int* __restrict__ mask_off,
-                int* __restrict__ total_tiles) {
+                int* __restrict__ seg_end) {
     __shared__ unsigned long long skeys[SORT_LDS_KEYS];
-    const int b = blockIdx.x;
-    const int cnt = cand_count[b * CNT_STRIDE];
-    unsigned long long* gk = keys + (size_t)b * key_stride;
-    for (int c = threadIdx.x; c < C; c += SORT_THREADS) {
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int cnt = cand_count[(b * G + g) * CNT_STRIDE];
+    int offset = 0;
+    for (int h = 0; h < g; ++h) offset += cand_count[(b * G + h) * CNT_STRIDE];
+    unsigned long long* raw = raw_keys + ((size_t)b * G + g) * raw_stride;
+    unsigned long long* gk = keys + (size_t)b * key_stride + offset;
+    // this group's classes: c*G/C == g
+    const int c_lo = (int)(((long long)g * C + G - 1) / G), c_hi = (int)(((long long)(g + 1) * C + G - 1) / G);
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += SORT_THREADS) {
         seg_start[b * C + c] = 0;
         seg_end[b * C + c] = 0;
     }
-    if (cnt == 0) {
-        if (threadIdx.x == 0) total_tiles[b] = 0;
-        return;
-    }
+    if (cnt == 0) return;
     int P = 1;
     while (P < cnt) P <<= 1;
     const unsigned long long* sorted;
     if (P <= SORT_LDS_KEYS) {
-        for (int i = threadIdx.x; i < P; i += SORT_THREADS) skeys[i] = (i < cnt) ? gk[i] : ~0ull;
+        for (int i = threadIdx.x; i < P; i += SORT_THREADS) skeys[i] = (i < cnt) ? raw[i] : ~0ull;
         __syncthreads();
         bitonic_sort(skeys, P);
-        for (int i = threadIdx.x; i < cnt; i += SORT_THREADS) gk[i] = skeys[i];
         sorted = skeys;
     } else {
         // more candidates than the LDS holds: same network in global memory
-        // (key_stride >= P is guaranteed by the host)
-        for (int i = cnt + threadIdx.x; i < P; i += SORT_THREADS) gk[i] = ~0ull;
+        // (raw_stride >= P is guaranteed by the host)
+        for (int i = cnt + threadIdx.x; i < P; i += SORT_THREADS) raw[i] = ~0ull;
         __threadfence_block();
         __syncthreads();
-        bitonic_sort(gk, P);
-        sorted = gk;
+        bitonic_sort(raw, P);
+        sorted = raw;
     }
-    // (seg_start/seg_end zeroing above is ordered before these writes by the
-    // barriers inside bitonic_sort, or by this one when P == 1)
+    // (the zeroing above is ordered before the writes below by the barriers
+    // inside bitonic_sort, or by this one when P == 1)
     __syncthreads();
     for (int i = threadIdx.x; i < cnt; i += SORT_THREADS) {
-        int c = key_cls(sorted[i]);
-        if (i == 0 || key_cls(sorted[i - 1]) != c) seg_start[b * C + c] = i;
-        if (i == cnt - 1 || key_cls(sorted[i + 1]) != c) seg_end[b * C + c] = i + 1;
+        const unsigned long long k = sorted[i];
+        gk[i] = k;
+        const int c = key_cls(k);
+        if (i == 0 || key_cls(sorted[i - 1]) != c) seg_start[b * C + c] = offset + i;
+        if (i == cnt - 1 || key_cls(sorted[i + 1]) != c) seg_end[b * C + c] = offset + i + 1;
     }
-    // Plan the suppression-matrix tiles: a segment of n boxes has T = ceil(n/64)
-    // word columns and T(T+1)/2 upper-triangular tiles of 64 mask words each.
-    // Exclusive prefix sums over the classes give every segment its first tile
-    // number and its mask offset.  (skeys is free now and serves as scratch.)
-    __syncthreads();
-    int* sa = reinterpret_cast<int*>(skeys);
-    int* sb = sa + SORT_THREADS;
+}
+
+// ---------------------------------------------------------------- plan
+// One workgroup per image plans the suppression-matrix tiles: a segment of n
+// boxes has T = ceil(n/64) word columns and T(T+1)/2 upper-triangular tiles of
+// 64 mask words each.  Exclusive prefix sums over the classes give every
+// segment its first tile number and its mask offset.
+__global__ void __launch_bounds__(SORT_THREADS)
+nms_plan_kernel(int C, const int* __restrict__ seg_start, const int* __restrict__ seg_end,
+                int* __restrict__ tile_base, int* __restrict__ mask_off, int* __restrict__ total_tiles) {
+    __shared__ int sa[SORT_THREADS], sb[SORT_THREADS];
+    const int b = blockIdx.x;
     int carry_t = 0, carry_w = 0;
     for (int c0 = 0; c0 < C; c0 += SORT_THREADS) {
         const int c = c0 + threadIdx.x;
@@ -541,7 +567,9 @@ rows8_gather_kernel(const unsigned long long* __restrict__ keys, const int* __re
 
 // ---------------------------------------------------------------- workspace
 struct NmsWorkspace {
-    int* cand_count;     // [B][CNT_STRIDE], one counter per 128-byte line
+    int* cand_count;     // [B][G][CNT_STRIDE], one counter per 128-byte line
+    unsigned long long* raw_keys;  // [B][G][raw_stride] candidate keys as compacted, per class group
+    int G, raw_stride;
     int* total;          // [1]  (lives in the caller's out_count instead when given)
     int* seg_start;      // [B*C]
     int* seg_end;        // [B*C]
@@ -561,12 +589,16 @@ struct NmsWorkspace {
     size_t zero_bytes;   // leading region that must be zeroed before every call
 };
 
+// candidate lists (= sort workgroups) per image
+static int class_groups(int C) { return C < 8 ? 1 : 8; }
+
 static NmsWorkspace carve(void* base, int B, int N, int C) {
     NmsWorkspace w;
+    w.G = class_groups(C);
     char* p = (char*)base;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* r = p + off; off = align_up(off + bytes, 256); return r; };
-    w.cand_count = (int*)take(sizeof(int) * (size_t)B * CNT_STRIDE);
+    w.cand_count = (int*)take(sizeof(int) * (size_t)B * w.G * CNT_STRIDE);
     w.zero_bytes = off;
     w.total = (int*)take(sizeof(int));
     const size_t S = (size_t)B * C;
@@ -576,6 +608,8 @@ static NmsWorkspace carve(void* base, int B, int N, int C) {
     w.seg_off = (int*)take(sizeof(int) * S);
     w.key_stride = (N <= SORT_LDS_KEYS) ? N : (int)next_pow2((uint32_t)N);
     w.keys = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)B * w.key_stride);
+    w.raw_stride = w.key_stride;
+    w.raw_keys = (unsigned long long*)take(sizeof(unsigned long long) * (size_t)B * w.G * w.raw_stride);
     w.boxes = (float4*)take(sizeof(float4) * (size_t)B * N);
     w.scores = (float*)take(sizeof(float) * (size_t)B * N);
     w.kept_pos = (int*)take(sizeof(int) * (size_t)B * N);
@@ -625,15 +659,16 @@ extern "C" int yolo_amd_filter_results(const float* pred, int B, int N, int D, i
     if (wave_lds * 2 <= 64 * 1024) {
         dim3 grid((N + 127) / 128, B);
         hipLaunchKernelGGL(nms_compact_kernel<2>, grid, dim3(128), wave_lds * 2, stream, pred, N, D, C,
-                           conf, w.key_stride, (int)wave_lds, w.cand_count, w.keys, w.boxes, w.scores);
+                           conf, w.raw_stride, w.G, (int)wave_lds, w.cand_count, w.raw_keys, w.boxes, w.scores);
     } else {
         dim3 grid((N + 63) / 64, B);
         hipLaunchKernelGGL(nms_compact_kernel<1>, grid, dim3(64), wave_lds, stream, pred, N, D, C,
-                           conf, w.key_stride, (int)wave_lds, w.cand_count, w.keys, w.boxes, w.scores);
+                           conf, w.raw_stride, w.G, (int)wave_lds, w.cand_count, w.raw_keys, w.boxes, w.scores);
     }
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(B), dim3(SORT_THREADS), 0, stream, w.cand_count,
-                       w.key_stride, C, w.keys, w.seg_start, w.seg_end, w.tile_base, w.mask_off,
-                       w.total_tiles);
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(w.G, B), dim3(SORT_THREADS), 0, stream, w.cand_count, w.G,
+                       w.raw_stride, w.raw_keys, w.key_stride, C, w.keys, w.seg_start, w.seg_end);
+    hipLaunchKernelGGL(nms_plan_kernel, dim3(B), dim3(SORT_THREADS), 0, stream, C, w.seg_start, w.seg_end,
+                       w.tile_base, w.mask_off, w.total_tiles);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, B), dim3(256), 0, stream, w.keys, w.key_stride,
                        N, C, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles, w.boxes, 1,
                        nms_thresh, w.mask, w.mask_stride);
@@ -669,10 +704,11 @@ extern "C" int yolo_amd_filter_img_class(const float* rows8, int m, float cls, f
     }
     YA_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, stream));
     hipLaunchKernelGGL(rows8_keys_kernel, dim3((m + 255) / 256), dim3(256), 0, stream, rows8, m, cls,
-                       w.cand_count, w.keys);
-    hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(SORT_THREADS), 0, stream, w.cand_count,
-                       w.key_stride, 1, w.keys, w.seg_start, w.seg_end, w.tile_base, w.mask_off,
-                       w.total_tiles);
+                       w.cand_count, w.raw_keys);
+    hipLaunchKernelGGL(nms_sort_kernel, dim3(1, 1), dim3(SORT_THREADS), 0, stream, w.cand_count, 1,
+                       w.raw_stride, w.raw_keys, w.key_stride, 1, w.keys, w.seg_start, w.seg_end);
+    hipLaunchKernelGGL(nms_plan_kernel, dim3(1), dim3(SORT_THREADS), 0, stream, 1, w.seg_start, w.seg_end,
+                       w.tile_base, w.mask_off, w.total_tiles);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, 1), dim3(256), 0, stream, w.keys, w.key_stride,
                        m, 1, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles,
                        reinterpret_cast<const float4*>(rows8), 2, nms_thresh, w.mask, w.mask_stride);
