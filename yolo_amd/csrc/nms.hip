@@ -188,17 +188,21 @@ nms_compact_kernel(const float* __restrict__ pred, int N, int D, int C, float co
     // Candidates go to one of G lists per image by class range (list g holds
     // the classes c with c*G/C == g), so that G workgroups can sort an image.
     const int grp = (int)(((long long)bi * G) / C);
+    // One atomic instruction per wave: lane g reserves the slots of list g
+    // (G <= 64), then every candidate reads its list's base from that lane.
+    unsigned long long mymask = 0;
+    int mycount = 0;
     for (int g = 0; g < G; ++g) {
         const unsigned long long m = __ballot(pass && grp == g);
-        if (m == 0) continue;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&cand_count[(b * G + g) * CNT_STRIDE], __popcll(m));
-        base = __shfl(base, 0);
-        if (pass && grp == g) {
-            const int row = row0 + lane;
-            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            raw_keys[((size_t)b * G + g) * raw_stride + slot] = make_key(bi, obj, row);
-        }
+        if (grp == g) mymask = m;
+        if (lane == g) mycount = __popcll(m);
+    }
+    int base = 0;
+    if (lane < G && mycount) base = atomicAdd(&cand_count[(b * G + lane) * CNT_STRIDE], mycount);
+    base = __shfl(base, grp);
+    if (pass) {
+        const int slot = base + __popcll(mymask & ((1ull << lane) - 1ull));
+        raw_keys[((size_t)b * G + grp) * raw_stride + slot] = make_key(bi, obj, row0 + lane);
     }
     if (pass) {
         float cx = r[0], cy = r[1], w = r[2], h = r[3];
