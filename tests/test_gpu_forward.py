@@ -84,6 +84,7 @@ CONV_CASES = [
     ("route_up_c64_c128", 2, 12, 64, 64, 1, 1, True, False, 128, 1, False),   # upsample + concat
     ("concat_k3_c64_c64", 1, 9, 64, 128, 3, 1, True, False, 64, 0, False),    # concat into 3x3
     ("big_m_tail", 5, 19, 64, 64, 3, 1, True, False, 0, 0, False),        # M = 1805, ragged tiles
+    ("thin_c32_n64_plain", 2, 37, 32, 64, 3, 1, False, False, 0, 0, False),   # thin kernel, ragged 8x16 tiles, linear
 ]
 
 
@@ -114,6 +115,24 @@ def test_conv_layer(case):
         torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
     else:
         torch.testing.assert_close(got, want, rtol=1.0 / 128, atol=1.0 / 128)
+
+
+@pytest.mark.parametrize("B,H,use_res", [(2, 40, True), (1, 21, False), (33, 16, True)])
+def test_thin_kernel_gives_the_im2col_kernels_bits(B, H, use_res, monkeypatch):
+    """3x3 32 -> 64 layers run in the persistent thin kernel; its K-steps are in the
+    im2col kernel's order, so the two must agree bit for bit."""
+    from gpu_helpers import run_conv
+    r = gi.rs(900 + H)
+    x0 = torch.from_numpy(r.standard_normal((B, H, H, 32)).astype(np.float32)).cuda().to(torch.bfloat16)
+    w = torch.from_numpy((r.standard_normal((64, 32, 3, 3)) * np.sqrt(2.0 / 288)).astype(np.float32))
+    bias = torch.from_numpy(r.normal(0, 0.3, 64).astype(np.float32))
+    res = None
+    if use_res:
+        res = torch.from_numpy(r.standard_normal((B, H, H, 64)).astype(np.float32)).cuda().to(torch.bfloat16)
+    thin = run_conv(x0, w, bias, leaky=True, residual=res)
+    monkeypatch.setenv("YOLO_AMD_THIN", "0")
+    generic = run_conv(x0, w, bias, leaky=True, residual=res)
+    assert torch.equal(thin.view(torch.int16), generic.view(torch.int16))
 
 
 # stride-1 3x3 layers on 13*2^n maps can take the patch-reuse kernel

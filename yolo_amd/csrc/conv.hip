@@ -1210,6 +1210,155 @@ conv_stem_kernel(const StemArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- thin 3x3 (32 -> 64 channels)
+// With 32 input channels a 3x3 layer has nine K-steps in all: as an im2col GEMM
+// every workgroup pays set-up and epilogue for a handful of MFMAs and re-reads
+// each input pixel nine times through the vector-memory path.  Here a persistent
+// workgroup keeps the layer's whole weight tensor (64 x 288 bf16) as MFMA
+// fragments in registers (72 per lane) and walks 8x16-pixel output tiles: the
+// 10x18-pixel input patch comes in once by LDS-DMA (64 bytes per pixel, whole
+// pixels per lane quad so every line is fetched once; the four 16-byte chunks
+// of pixel slot s sit at position chunk ^ ((s >> 2) & 3), which spreads the 16
+// pixels a tap reads over the banks), double buffered so the next tile streams
+// in behind the MFMAs; the residual tile is
+// fetched by LDS-DMA during the taps; output as in the other kernels (one
+// rounding, 16-byte stores).  K-steps in tap order: the same accumulators as the
+// im2col kernel gives.  The layer is bound by its HBM traffic.
+constexpr int THIN_TY = 8, THIN_TX = 16;
+constexpr int THIN_PR = THIN_TY + 2, THIN_PC = THIN_TX + 2;          // 10 x 18 input pixels
+constexpr int THIN_SLOTS = 192;                                      // 180 used: twelve LDS-DMA instructions of 16 pixels
+constexpr int THIN_PATCH = THIN_SLOTS * 64;                          // 12 KiB
+constexpr int THIN_TILE = THIN_TY * THIN_TX * 64 * 2;                // 16 KiB output tile
+
+struct ThinArgs {
+    const __bf16* src;     // (B, H, W, 32)
+    const __bf16* wgt;     // [9][64][32]
+    const float* bias;
+    const __bf16* res;     // (B, H, W, 64) or null
+    __bf16* dst;           // (B, H, W, 64)
+    const __bf16* zero;
+    int B, H, W, leaky;
+    int tiles_x, tiles_y;
+};
+
+__global__ void __launch_bounds__(256)
+conv3x3_thin_kernel(const ThinArgs a) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * THIN_PATCH + THIN_TILE];
+    char* const tile = lds + 2 * THIN_PATCH;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int wpx = w & 1, wch = w >> 1;               // pixel half (4 rows), channel half (32)
+
+    bf16x8 wf[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+            wf[tap][tc] = *reinterpret_cast<const bf16x8*>(a.wgt + ((tap * 64 + wch * 32 + tc * 16 + n) * 32 + q * 8));
+
+    // patch fill: instruction j (of 12) covers pixel slots 16j..16j+15, four lanes per pixel;
+    // wave w issues j = w, w+4, w+8
+    int prow[3], pcol[3], pchunk[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int sl = 16 * (w + 4 * i) + (lane >> 2);
+        prow[i] = sl < THIN_PR * THIN_PC ? sl / THIN_PC : -100000;   // unused slots read the zero page
+        pcol[i] = sl - (sl / THIN_PC) * THIN_PC;
+        pchunk[i] = ((lane & 3) ^ ((sl >> 2) & 3)) * 8;
+    }
+    const int per_image = a.tiles_x * a.tiles_y, ntiles = per_image * a.B;
+    auto issue_patch = [&](int t, int buf) {
+        const int b = t / per_image, t2 = t - b * per_image;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int y0 = ty * THIN_TY - 1, x0 = tx * THIN_TX - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int iy = y0 + prow[i], ix = x0 + pcol[i];
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const __bf16* p = ok ? a.src + (((size_t)b * a.H + iy) * a.W + ix) * 32 + pchunk[i] : a.zero;
+            lds_dma16(p, lds + buf * THIN_PATCH + (w + 4 * i) * 1024);
+        }
+    };
+    if ((int)blockIdx.x >= ntiles) return;
+    const int step = gridDim.x;
+    issue_patch(blockIdx.x, 0);
+    int buf = 0;
+    const int cq = q * 4;
+    for (int t = blockIdx.x; t < ntiles; t += step, buf ^= 1) {
+        const int b = t / per_image, t2 = t - b * per_image;
+        const int oy0 = (t2 / a.tiles_x) * THIN_TY, ox0 = (t2 % a.tiles_x) * THIN_TX;
+        auto pix = [&](int slot) -> long long {
+            const int y = oy0 + slot / THIN_TX, x = ox0 + slot % THIN_TX;
+            return (y < a.H && x < a.W) ? ((long long)b * a.H + y) * a.W + x : -1;
+        };
+        wait_vmcnt<0>();                               // this tile's patch (and the stores of the last tile)
+        __builtin_amdgcn_s_barrier();                  // ... everyone's; the output tile region is free again
+        asm volatile("" ::: "memory");
+        const bool more = t + step < ntiles;
+        if (a.res) {
+            // residual tile first (awaited first), then the next tile's patch
+            constexpr int NINST = THIN_TY * THIN_TX * 8 / 64;            // 16 instructions, 4 per wave
+#pragma unroll
+            for (int i = 0; i < NINST / 4; ++i) {
+                const int j = w + 4 * i;
+                const int row = j * 8 + lane / 8;
+                const int c = (lane % 8) ^ (row & 7);
+                const long long m = pix(row);
+                lds_dma16(m >= 0 ? a.res + (size_t)m * 64 + c * 8 : a.zero, tile + j * 1024);
+            }
+        }
+        if (more) issue_patch(t + step, buf ^ 1);
+
+        const char* pb = lds + buf * THIN_PATCH;
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            bf16x8 xf[4];
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                const int sl = (wpx * 4 + tp + kh) * THIN_PC + n + kw;
+                xf[tp] = *reinterpret_cast<const bf16x8*>(pb + sl * 64 + ((q ^ ((sl >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp)
+                    acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap][tc], xf[tp], acc[tc][tp], 0, 0, 0);
+        }
+        if (a.res) {
+            if (more) wait_vmcnt<3>();                 // the residual has landed; the next patch may still fly
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const int slot = (wpx * 4 + tp) * THIN_TX + n;
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                const int chl = wch * 32 + tc * 16 + cq;
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + chl);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[tc][tp][r] + bs[r];
+                    if (a.leaky) x = x > 0.f ? x : 0.1f * x;
+                    v[r] = x;
+                }
+                tile_put<64>(tile, slot, chl, v, a.res != nullptr);
+            }
+        }
+        __syncthreads();
+        tile_store<THIN_TY * THIN_TX, 64, 256>(tile, a.dst, 64, 0, pix);
+    }
+}
+
 // ---------------------------------------------------------------- launch
 static int pick_bk(int c0, int c1) { return (c0 % 64 == 0 && c1 % 64 == 0) ? 64 : 32; }
 static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
@@ -1289,6 +1438,19 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     YA_REQUIRE(d.cout_pad % BN == 0 && d.cout_pad >= d.cout, "conv: cout_pad=%d not a multiple of %d", d.cout_pad, BN);
     YA_REQUIRE((long long)d.B * d.H * d.W * (d.c0 + d.c1) < (1ll << 31) && (long long)d.cout_pad * K < (1ll << 31),
                "conv: tensor too large for 32-bit element offsets");
+    // 3x3 stride-1 32 -> 64 channels: the thin kernel (YOLO_AMD_THIN=0: development knob)
+    if (d.ksize == 3 && d.stride == 1 && d.c0 == 32 && d.c1 == 0 && d.up0 == 0 && d.cout == 64 &&
+        d.cout_pad == 64 && !d.dst_fp32 && env_int("YOLO_AMD_THIN", 1)) {
+        ThinArgs t;
+        t.src = (const __bf16*)d.src0; t.wgt = (const __bf16*)d.weight; t.bias = d.bias;
+        t.res = (const __bf16*)d.residual; t.dst = (__bf16*)d.dst; t.zero = (const __bf16*)zero_page;
+        t.B = d.B; t.H = d.H; t.W = d.W; t.leaky = d.leaky;
+        t.tiles_x = (d.W + THIN_TX - 1) / THIN_TX; t.tiles_y = (d.H + THIN_TY - 1) / THIN_TY;
+        const long long ntiles = (long long)t.tiles_x * t.tiles_y * d.B;
+        hipLaunchKernelGGL(conv3x3_thin_kernel, dim3((unsigned)std::min<long long>(ntiles, 256 * 2)), dim3(256), 0,
+                           stream, t);
+        return YA_OK;
+    }
     // Stride-1 3x3 layers on 13*2^n feature maps can take the patch-reuse kernel.
     // Measured at batch 32 (tools/conv_bench.py): with two to six 13x13 tiles per
     // CU (52x52 and 26x26 maps) its eight-wave form wins, with more (104x104) the
