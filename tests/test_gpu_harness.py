@@ -83,3 +83,32 @@ def test_confidence_sweep_with_one_nms(mode, ties, C):
             if ref.shape[0]:
                 assert np.all(np.diff(got_bc[:, 4]) >= 0)
                 assert_bit_equal(np.sort(got_bc, axis=0), np.sort(ref, axis=0), f"image {b} class {c}")
+
+
+def test_detection_pipeline_returns_what_the_two_calls_return():
+    from gpu_helpers import build_model
+    from yolo_amd.harness import DetectionPipeline
+    from yolo_amd.utilis import filter_results
+    model, params, _ = build_model(96)
+    params = dict(params)
+    params["confidence"], params["nms_thesh"] = 0.3, 0.4
+    batches = [torch.from_numpy(gi.images(50 + i, 3, 96)).cuda() for i in range(5)]
+    want = []
+    for x in batches:
+        out = filter_results(model(x), params)
+        want.append(out if isinstance(out, int) else out.clone())
+    pipe = DetectionPipeline(model, params)
+    got = []
+    for x in batches:
+        done = pipe.submit(x)
+        if done is not None:
+            got.append(done if isinstance(done, int) else done.clone())
+    last = pipe.flush()
+    got.append(last if isinstance(last, int) else last.clone())
+    assert pipe.flush() is None
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        if isinstance(w, int):
+            assert isinstance(g, int) and g == 0
+        else:
+            assert torch.equal(g.view(torch.int32), w.view(torch.int32))

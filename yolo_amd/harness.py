@@ -7,6 +7,9 @@ letterboxed network frame back to every original image and clamp them
 a list of (by default) 30 values (/root/reference/evaluate.py:185-207,
 /root/reference/utilis.py:688).  The functions here do the same work on the GPU:
 the rescale as one HIP kernel over all rows, the confidence sweep with ONE NMS.
+``DetectionPipeline`` is the callers' batch loop (detection.py:43-50,
+video.py:60-66) with the NMS of one batch running on a second HIP stream beside
+the forward pass of the next.
 """
 from __future__ import annotations
 
@@ -88,3 +91,79 @@ def detections_by_conf(prediction, params, conf_list):
                     images[b][c] = rb[rb[:, 7] == c][:, 1:6]
         result.append(images)
     return result
+
+
+class DetectionPipeline:
+    """The callers' loop ``for images in loader: prediction = model(images);
+    output = filter_results(prediction, params)`` (detection.py:43-50) as a two-stage
+    pipeline: the forward pass runs on the current stream, the NMS of the same batch on
+    a side stream, so it overlaps the forward pass of the next batch.  Results come
+    back in submission order and are the tensors filter_results would have returned.
+
+        pipe = DetectionPipeline(model, params)
+        for images in loader:
+            done = pipe.submit(images)       # None for the first batch, else the previous batch's output
+            ...
+        last = pipe.flush()
+
+    The (K, 9) tensor handed out is a view of one of two internal buffers: it stays
+    valid until the second submit() after it was returned; clone it to keep it longer.
+    """
+
+    def __init__(self, model, params):
+        _lib.require_gpu()
+        self.model, self.params = model, params
+        self.device = next(model.parameters()).device
+        self.side = torch.cuda.Stream(device=self.device)
+        self._slot = 0
+        self._pending = None            # (slot, event) of the batch whose NMS is in flight
+        self._bufs = None
+
+    def _alloc(self, B, N, C):
+        if self._bufs is None or self._bufs["shape"] != (B, N, C):
+            nbytes = lib.yolo_amd_filter_results_workspace_bytes(B, N, C)
+            self._bufs = dict(
+                shape=(B, N, C),
+                ws=torch.empty(nbytes, dtype=torch.uint8, device=self.device),
+                rows=[torch.empty((B * N, 9), dtype=torch.float32, device=self.device) for _ in range(2)],
+                cnt=[torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(2)],
+                host=[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)])
+        return self._bufs
+
+    def _collect(self):
+        if self._pending is None:
+            return None
+        slot, ev = self._pending
+        self._pending = None
+        ev.synchronize()
+        k = int(self._bufs["host"][slot].item())
+        return self._bufs["rows"][slot][:k] if k else 0
+
+    def submit(self, images):
+        """Launch forward + NMS for `images`; returns the finished output of the batch
+        submitted before this one (None if there was none)."""
+        main = torch.cuda.current_stream(self.device)
+        pred = self.model(images)                       # forward of this batch: overlaps the pending NMS
+        B, N, D = pred.shape
+        C = int(self.params["num_classes"])
+        bufs = self._alloc(B, N, C)
+        previous = self._collect()                      # also frees the workspace for this batch's NMS
+        slot = self._slot
+        self._slot ^= 1
+        self.side.wait_stream(main)
+        pred.record_stream(self.side)
+        with torch.cuda.device(self.device), torch.cuda.stream(self.side):
+            check(lib.yolo_amd_filter_results(pred.data_ptr(), B, N, D, C, float(self.params["confidence"]),
+                                              float(self.params["nms_thesh"]), bufs["ws"].data_ptr(),
+                                              bufs["ws"].numel(), bufs["rows"][slot].data_ptr(),
+                                              bufs["cnt"][slot].data_ptr(), self.side.cuda_stream),
+                  "filter_results")
+            bufs["host"][slot].copy_(bufs["cnt"][slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self._pending = (slot, ev)
+        return previous
+
+    def flush(self):
+        """Output of the last submitted batch (None if nothing is pending)."""
+        return self._collect()
