@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--conf", type=float, default=0.5)
     ap.add_argument("--nms", type=float, default=0.4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the extra pipelined measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,7 +187,7 @@ def main():
             print(f"[bench] gather_detections failed on rank {rank}: {exc}", file=sys.stderr, flush=True)
 
     pipelined = None
-    if world == 1:
+    if world == 1 and not args.no_pipelined:
         from yolo_amd.harness import DetectionPipeline
         pipe = DetectionPipeline(model, params)
         for _ in range(args.warmup):

@@ -7,7 +7,7 @@ STEPS=5; WARM=2
 mkdir -p gpurun_out/pmcb
 run() {
   name=$1; shift
-  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmcb/$name -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > gpurun_out/pmcb/$name.log 2>&1 || { echo "pass $name failed"; tail -5 gpurun_out/pmcb/$name.log; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmcb/$name -- python bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-pipelined > gpurun_out/pmcb/$name.log 2>&1 || { echo "pass $name failed"; tail -5 gpurun_out/pmcb/$name.log; exit 1; }
 }
 run rd TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum && \
 run wr TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum && \
