@@ -175,3 +175,37 @@ def _some_zero_obj(pred):
 
 EDITS = {"single_box": _single_box, "middle_empty": _middle_empty,
          "overflow": _overflow, "some_zero_obj": _some_zero_obj}
+
+
+# ------------------------------------------------------------------ mAP scoring
+def eval_case(seed, B, N, C, H=416, L=12, hit=0.7):
+    """A data-set batch for the scoring code: labels (list of B arrays (L, 5)
+    [class, cx, cy, w, h] in fractions of H, zero rows as padding, one image with no
+    label at all when B > 2) and a decoded prediction (B, N, 5+C) whose first rows
+    are jittered copies of the labelled boxes (a share `hit` of them with the right
+    class), the rest clutter with low objectness."""
+    r = rs(seed)
+    pred = nms_pred(seed + 1000, B, N, C, H=H)
+    pred[:, :, 4] *= 0.35
+    labels = []
+    for b in range(B):
+        lab = np.zeros((L, 5), dtype=np.float64)
+        n = 0 if (B > 2 and b == 1) else int(r.randint(1, L + 1))
+        cls = r.randint(0, C, n)
+        cxy = r.uniform(0.15, 0.85, (n, 2))
+        wh = r.uniform(0.05, 0.3, (n, 2))
+        lab[:n, 0] = cls
+        lab[:n, 1:3] = cxy
+        lab[:n, 3:5] = wh
+        labels.append(lab)
+        for k in range(n):
+            for rep in range(2):          # two detections per object: one must lose
+                row = pred[b, 2 * k + rep]
+                jit = r.normal(0, 0.02 + 0.05 * rep, 4)
+                row[0:2] = (cxy[k] + jit[:2]) * H
+                row[2:4] = wh[k] * (1 + jit[2:]) * H
+                row[4] = r.uniform(0.3, 1.0)
+                row[5:] = r.uniform(0, 0.3, C)
+                right = r.uniform() < hit
+                row[5 + (cls[k] if right else r.randint(0, C))] = r.uniform(0.6, 1.0)
+    return pred.astype(np.float32), labels

@@ -112,3 +112,23 @@ def test_detection_pipeline_returns_what_the_two_calls_return():
             assert isinstance(g, int) and g == 0
         else:
             assert torch.equal(g.view(torch.int32), w.view(torch.int32))
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("name", ["coco_sweep", "four_class", "single_conf"])
+def test_get_map_with_hip_detections_matches_the_reference(name, train):
+    """evaluate.get_map end to end on stored predictions: NMS through the library,
+    scoring in numpy; every returned number equals what the reference's get_map
+    returned on the same data (golden_eval.json)."""
+    import contextlib
+    import io
+    from eval_data import CASES, ReplayModel, batches, check_against_golden
+    from yolo_amd import evaluate as ev
+    _, _, _, _, C, H, confs = CASES[name]
+    data = batches(name)
+    params = default_params(height=H, num_classes=C, cuda=True)
+    params["specific_conf"] = 0.5
+    model = ReplayModel(params, [d["pred"] for d in data], device="cuda")
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = ev.get_map(model, data, train=train, confidence=confs if confs else False)
+    check_against_golden(name, res, train)
