@@ -209,3 +209,29 @@ def eval_case(seed, B, N, C, H=416, L=12, hit=0.7):
                 right = r.uniform() < hit
                 row[5 + (cls[k] if right else r.randint(0, C))] = r.uniform(0.6, 1.0)
     return pred.astype(np.float32), labels
+
+
+# ------------------------------------------------------------------ anchor k-means
+def label_dims(seed, n, clusters=5):
+    """(n, 2) label widths/heights as fractions of the image: a mixture of
+    `clusters` log-normal blobs, plus a few exact duplicates and equal-side boxes so
+    the tie branches of the overlap formula are taken."""
+    r = rs(seed)
+    centres = r.uniform(0.04, 0.6, (clusters, 2))
+    which = r.randint(0, clusters, n)
+    d = centres[which] * np.exp(r.normal(0, 0.25, (n, 2)))
+    d = np.round(np.clip(d, 0.005, 0.99), 4)
+    d[1] = d[0]
+    d[3, 0] = d[2, 0]
+    d[5, 1] = d[4, 1]
+    return d
+
+
+def write_label_csv(path, dims, seed=0):
+    """A label file in the layout generate_anchor reads: width and height are the
+    fifth and sixth columns (img_name, c, x, y, w, h)."""
+    r = rs(seed)
+    with open(path, "w") as fh:
+        fh.write("img_name,c,x,y,w,h\n")
+        for k, (w, h) in enumerate(dims):
+            fh.write(f"img{k % 37}.jpg,{r.randint(0, 4)},{r.uniform():.4f},{r.uniform():.4f},{float(w)!r},{float(h)!r}\n")
