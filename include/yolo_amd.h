@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define YOLO_AMD_ABI_VERSION 3
+#define YOLO_AMD_ABI_VERSION 4
 #define YOLO_AMD_MAX_HEADS 4
 #define YOLO_AMD_MAX_ANCHORS 8
 
@@ -101,6 +101,42 @@ int yolo_amd_filter_img_class(const float* rows8, int m, float cls, float nms_th
  * im_dims: (B, 2) fp32 on the device, original (width, height) per image. */
 int yolo_amd_rescale_boxes(float* rows9, int K, const float* im_dims, int B, float height,
                            void* stream);
+
+/* ---------------------------------------------------------------- caller pre-processing
+ * Replaces the image transforms the callers apply before model(images):
+ *   LetterBoxImage_cv / LetterboxImage / letterbox_image
+ *                              /root/reference/utilis.py:69-86, 89-104, 495-509
+ *   ImgToTensorCv              /root/reference/utilis.py:107-116
+ *   transforms.Normalize       /root/reference/detection.py:34-35
+ *   prep_image                 /root/reference/utilis.py:512-516
+ *
+ * images: HOST array of `batch` descriptors of frames in DEVICE memory, 8-bit,
+ * three interleaved channels in cv2.imread's order (BGR).  Each frame is resized
+ * with its aspect kept (bicubic, OpenCV's 8-bit fixed-point INTER_CUBIC, no
+ * antialiasing) onto an inp_dim x inp_dim canvas of grey 128.
+ * flags: YOLO_AMD_PRE_MINMAX  (canvas - min) / (max - min) in float64 per image,
+ *                             as LetterBoxImage_cv does (a flat canvas gives NaN);
+ *        YOLO_AMD_PRE_DIV255  float32 / 255 as prep_image does; not both.
+ * mean3/std3: HOST, three floats each in RGB order, or both NULL: (x - mean) / std.
+ * dst: (batch, 3, inp_dim, inp_dim) fp32 on the device, channels RGB; may be NULL
+ *      when only the canvas is wanted.
+ * canvas_out: optional (batch, inp_dim, inp_dim, 3) uint8 on the device, the
+ *      letterboxed frames before normalisation (what LetterboxImage returns);
+ *      NULL keeps them in the workspace.
+ * Fails with a message when a frame shrinks to zero width or height. */
+typedef struct yolo_amd_image {
+    const void* data;      /* device pointer to the first pixel */
+    int32_t width, height;
+    int64_t pitch_bytes;   /* distance between rows, >= 3 * width */
+} yolo_amd_image;
+
+#define YOLO_AMD_PRE_MINMAX 1
+#define YOLO_AMD_PRE_DIV255 2
+
+size_t yolo_amd_preprocess_workspace_bytes(int batch, int inp_dim);
+int yolo_amd_preprocess(const yolo_amd_image* images, int batch, int inp_dim, int flags,
+                        const float* mean3, const float* std3, float* dst, uint8_t* canvas_out,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- conv stack
  * Replaces the conv / upsample / route / shortcut arms of yolo_v3.forward

@@ -21,6 +21,14 @@ Reference lines restated here:
   filter_img_class     /root/reference/utilis.py:355-390
   filter_results       /root/reference/utilis.py:393-465
   rescale block        /root/reference/detection.py:52-70 (= video.py:78-91)
+  image transforms     /root/reference/utilis.py:69-116, 495-516 and the Normalize
+                       of /root/reference/detection.py:31-35.  The pad / min-max /
+                       channel flip / mean-std part is pinned (golden_pre.npz holds
+                       what numpy and torch return for the reference's statements).
+                       The cubic resize is cv2.resize, which is not installed here
+                       and which the reference holds no output of: resize_cubic_u8
+                       restates OpenCV's published 8-bit fixed-point algorithm and
+                       its parity with cv2 is UNPINNED.
 """
 from __future__ import annotations
 
@@ -396,3 +404,101 @@ def filter_results_multi(pred, conf_list, nms_thresh, num_classes):
     """What evaluate.get_map does per batch (evaluate.py:185-192): filter_results
     once per confidence of the list.  Returns [rows or 0 per confidence]."""
     return [filter_results(pred, float(c), nms_thresh, num_classes) for c in conf_list]
+
+
+# --------------------------------------------------------------------------
+# image transforms of the callers
+# --------------------------------------------------------------------------
+def letterbox_geometry(img_w, img_h, w, h):
+    """Size and offset of the resized image inside the w x h canvas, in Python
+    doubles as the reference computes them (utilis.py:75-81)."""
+    new_w = int(img_w * min(w / img_w, h / img_h))
+    new_h = int(img_h * min(w / img_w, h / img_h))
+    return new_w, new_h, (w - new_w) // 2, (h - new_h) // 2
+
+
+def _cubic_taps(n_dst, n_src):
+    """Per destination coordinate: first-tap source index minus nothing (the taps
+    are src[s-1 .. s+2], clamped to the image) and the four 11-bit fixed-point
+    weights.  OpenCV resize, INTER_CUBIC, 8-bit: position (d + 0.5) * scale - 0.5
+    in double, rounded to float; Keys kernel with A = -0.75 in float; weights
+    scaled by 2048 and rounded half-to-even to int16.  PARITY WITH cv2 UNPINNED."""
+    scale = 1.0 / (n_dst / n_src)
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    x = (f - s.astype(np.float32)).astype(np.float32)
+    A, one = np.float32(-0.75), np.float32(1.0)
+    xp = x + one
+    c0 = ((A * xp - np.float32(5) * A) * xp + np.float32(8) * A) * xp - np.float32(4) * A
+    c1 = ((A + np.float32(2)) * x - (A + np.float32(3))) * x * x + one
+    om = one - x
+    c2 = ((A + np.float32(2)) * om - (A + np.float32(3))) * om * om + one
+    c3 = one - c0 - c1 - c2
+    wts = np.stack([c0, c1, c2, c3], 1).astype(np.float32) * np.float32(2048)
+    wts = np.clip(np.rint(wts), -32768, 32767).astype(np.int64)
+    return s, wts
+
+
+def resize_cubic_u8(img, new_w, new_h):
+    """(h, w, c) uint8 -> (new_h, new_w, c) uint8, bicubic without antialiasing:
+    horizontal pass into integers, vertical pass, one rounding shift by 22 bits,
+    saturation to 0..255; taps outside the image repeat the border pixel."""
+    img = np.asarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 3
+    h, w, _ = img.shape
+    sx, ax = _cubic_taps(new_w, w)
+    sy, ay = _cubic_taps(new_h, h)
+    src = img.astype(np.int64)
+    rows = np.zeros((h, new_w, img.shape[2]), dtype=np.int64)
+    for k in range(4):
+        rows += src[:, np.clip(sx + k - 1, 0, w - 1), :] * ax[None, :, k, None]
+    out = np.zeros((new_h, new_w, img.shape[2]), dtype=np.int64)
+    for k in range(4):
+        out += rows[np.clip(sy + k - 1, 0, h - 1)] * ay[:, k, None, None]
+    return np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+
+
+def letterbox_canvas(resized, w, h):
+    """utilis.py:80-82 / 497-507: integer canvas of 128 with the resized image in
+    the middle (the canvas is int64 in the reference; values fit a byte)."""
+    new_h, new_w = resized.shape[:2]
+    canvas = np.full((h, w, resized.shape[2]), 128)
+    top, left = (h - new_h) // 2, (w - new_w) // 2
+    canvas[top:top + new_h, left:left + new_w, :] = resized
+    return canvas
+
+
+def canvas_to_input(canvas, minmax=True, div255=False, mean=None, std=None):
+    """Canvas (h, w, 3) BGR integers -> (3, h, w) float32 RGB network input.
+    minmax: LetterBoxImage_cv's float64 (c - min) / (max - min) (utilis.py:85), then
+    the float32 conversion of ImgToTensorCv (:107-116).  div255: prep_image's
+    float32 division (:512-516).  mean/std: torchvision Normalize as detection.py
+    :34-35 applies it, float32 subtract then float32 divide per channel."""
+    canvas = np.asarray(canvas).astype(np.int64)
+    if minmax:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            val = (canvas - canvas.min()) / (canvas.max() - canvas.min())
+    else:
+        val = canvas
+    t = np.ascontiguousarray(val[:, :, ::-1].transpose(2, 0, 1)).astype(np.float32)
+    if div255:
+        t = t / np.float32(255.0)
+    if mean is not None:
+        m = np.asarray(mean, dtype=np.float32)[:, None, None]
+        s = np.asarray(std, dtype=np.float32)[:, None, None]
+        t = (t - m) / s
+    return t.astype(np.float32)
+
+
+def preprocess(images, inp_dim, minmax=True, div255=False, mean=None, std=None):
+    """The detection data pipeline for a list of (h, w, 3) uint8 BGR images:
+    returns ((B, 3, H, H) float32, [canvases], (B, 2) original (w, h))."""
+    outs, canvases, dims = [], [], []
+    for img in images:
+        ih, iw = img.shape[:2]
+        new_w, new_h, _, _ = letterbox_geometry(iw, ih, inp_dim, inp_dim)
+        canvas = letterbox_canvas(resize_cubic_u8(img, new_w, new_h), inp_dim, inp_dim)
+        canvases.append(canvas.astype(np.uint8))
+        outs.append(canvas_to_input(canvas, minmax, div255, mean, std))
+        dims.append((iw, ih))
+    return np.stack(outs), canvases, np.array(dims, dtype=np.float32)

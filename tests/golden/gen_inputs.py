@@ -235,3 +235,18 @@ def write_label_csv(path, dims, seed=0):
         fh.write("img_name,c,x,y,w,h\n")
         for k, (w, h) in enumerate(dims):
             fh.write(f"img{k % 37}.jpg,{r.randint(0, 4)},{r.uniform():.4f},{r.uniform():.4f},{float(w)!r},{float(h)!r}\n")
+
+
+# ------------------------------------------------------------------ image transforms
+def photo(seed, w, h, lo=0, hi=256):
+    """(h, w, 3) uint8 BGR test image: smooth gradients, a few hard-edged rectangles
+    and noise, so cubic overshoot (clipping at 0 and 255) happens."""
+    r = rs(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 120 * np.sin(xx / (7.0 + c) + yy / (11.0 + 2 * c)) for c in range(3)], 2)
+    for _ in range(6):
+        x0, y0 = r.randint(0, w), r.randint(0, h)
+        x1, y1 = x0 + r.randint(1, max(2, w // 3)), y0 + r.randint(1, max(2, h // 3))
+        img[y0:y1, x0:x1] = r.choice([0, 255], 3)
+    img += r.normal(0, 6, img.shape)
+    return np.clip(img, lo, hi - 1).astype(np.uint8)

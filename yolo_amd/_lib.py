@@ -31,6 +31,12 @@ class HeadDesc(ctypes.Structure):
     ]
 
 
+class ImageDesc(ctypes.Structure):
+    """yolo_amd_image of include/yolo_amd.h."""
+    _fields_ = [("data", ctypes.c_void_p), ("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("pitch_bytes", ctypes.c_int64)]
+
+
 class ConvDesc(ctypes.Structure):
     _fields_ = [
         ("src0", ctypes.c_void_p),
@@ -75,6 +81,11 @@ SYMBOLS = {
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "yolo_amd_rescale_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
+    "yolo_amd_preprocess_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "yolo_amd_preprocess": (ctypes.c_int, [ctypes.POINTER(ImageDesc), ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_size_t, ctypes.c_void_p]),
     "yolo_amd_conv_cout_pad": (ctypes.c_int, [ctypes.c_int]),
     "yolo_amd_conv_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p]),
@@ -98,7 +109,7 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    want = 3
+    want = 4
     got = lib.yolo_amd_abi_version()
     if got != want:
         raise ImportError(f"{LIB_PATH} has ABI version {got}, the Python side expects {want}")

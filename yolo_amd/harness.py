@@ -42,6 +42,69 @@ def rescale_detections(output, im_dim_list, height):
     return rows if dev_in.type == "cuda" else rows.to(dev_in)
 
 
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def preprocess_frames(frames, inp_dim, minmax=True, div255=False, mean=None, std=None,
+                      return_canvas=False, device=None):
+    """Raw frames to the network input on the GPU: what the data set of detection.py
+    does per image on the host with LetterBoxImage_cv -> ImgToTensorCv -> Normalize
+    (/root/reference/detection.py:31-35, /root/reference/utilis.py:69-116), or
+    prep_image with minmax=False, div255=True (/root/reference/utilis.py:512-516).
+
+    frames: sequence of (h, w, 3) uint8 BGR arrays as cv2.imread returns them, or
+    uint8 torch tensors of that shape (device tensors are read where they are; host
+    arrays are uploaded).  Returns (images, im_dim_list): images is the (B, 3,
+    inp_dim, inp_dim) float32 device tensor model(images) takes, im_dim_list the
+    [(width, height), ...] list the rescale step takes.  With return_canvas the
+    letterboxed uint8 frames (B, inp_dim, inp_dim, 3) come as a third value (what
+    LetterboxImage returns, /root/reference/utilis.py:89-104).
+
+    The resize is OpenCV's 8-bit INTER_CUBIC arithmetic restated in the kernel; cv2
+    itself was not available to compare against, so treat a one-level difference
+    from cv2.resize in a small share of pixels as possible."""
+    import ctypes
+    _lib.require_gpu()
+    if len(frames) == 0:
+        raise ValueError("preprocess_frames: no frames")
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    held, descs, dims = [], (_lib.ImageDesc * len(frames))(), []
+    for i, f in enumerate(frames):
+        t = f if isinstance(f, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(f))
+        if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+            raise ValueError(f"frame {i}: expected (h, w, 3) uint8, got {tuple(t.shape)} {t.dtype}")
+        if t.stride(2) != 1 or t.stride(1) != 3:
+            t = t.contiguous()
+        t = t.to(dev, non_blocking=True)
+        held.append(t)
+        descs[i].data = t.data_ptr()
+        descs[i].height, descs[i].width = int(t.shape[0]), int(t.shape[1])
+        descs[i].pitch_bytes = int(t.stride(0))
+        dims.append((int(t.shape[1]), int(t.shape[0])))
+    B, H = len(frames), int(inp_dim)
+    images = torch.empty((B, 3, H, H), dtype=torch.float32, device=dev)
+    canvas = torch.empty((B, H, H, 3), dtype=torch.uint8, device=dev) if return_canvas else None
+    flags = (1 if minmax else 0) | (2 if div255 else 0)
+    m = (ctypes.c_float * 3)(*mean) if mean is not None else None
+    sd = (ctypes.c_float * 3)(*std) if std is not None else None
+    nbytes = lib.yolo_amd_preprocess_workspace_bytes(B, H)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.yolo_amd_preprocess(descs, B, H, flags, m, sd, images.data_ptr(),
+                                      canvas.data_ptr() if canvas is not None else None,
+                                      ws.data_ptr(), nbytes, _lib.current_stream_ptr(dev)),
+              "preprocess")
+    # the frames and the workspace are read by kernels queued on the current stream
+    stream = torch.cuda.current_stream(dev)
+    for t in held:
+        t.record_stream(stream)
+    ws.record_stream(stream)
+    return (images, dims, canvas) if return_canvas else (images, dims)
+
+
 def filter_results_multi(prediction, params, conf_list):
     """filter_results(prediction, params) for every confidence of conf_list, as
     evaluate.get_map asks for it (evaluate.py:185-192), with one NMS instead of
