@@ -40,6 +40,29 @@ def main():
     src_rows = min(a.h, 4 * nh)
     src_bytes = src_rows * min(a.w, 4 * nw) * 3
     alg = a.batch * (src_bytes + 2 * a.side * a.side * 3 + a.side * a.side * 12)
+    # the library call alone, descriptors prepared once
+    import ctypes
+    from yolo_amd import _lib
+    descs = (_lib.ImageDesc * a.batch)()
+    for i, t in enumerate(frames):
+        descs[i].data, descs[i].width, descs[i].height, descs[i].pitch_bytes = t.data_ptr(), a.w, a.h, t.stride(0)
+    out = torch.empty((a.batch, 3, a.side, a.side), device="cuda")
+    n = _lib.lib.yolo_amd_preprocess_workspace_bytes(a.batch, a.side)
+    ws = torch.empty(n, dtype=torch.uint8, device="cuda")
+    m, sd = (ctypes.c_float * 3)(*IMAGENET_MEAN), (ctypes.c_float * 3)(*IMAGENET_STD)
+    st = _lib.current_stream_ptr(out.device)
+    call = lambda: _lib.lib.yolo_amd_preprocess(descs, a.batch, a.side, 1, m, sd, out.data_ptr(), None,
+                                                ws.data_ptr(), n, st)
+    for _ in range(5):
+        assert call() == 0
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(a.iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    us_lib = e0.elapsed_time(e1) * 1e3 / a.iters
+    print(f"library call alone: {us_lib:.1f} us, {alg / us_lib / 1e3:.1f} GB/s")
     print(f"{a.batch} frames {a.w}x{a.h} -> {a.side}: {us:.1f} us/call, "
           f"{a.batch / us * 1e6:.0f} frames/s, {alg / us / 1e3:.1f} GB/s of {alg / 1e6:.1f} MB")
 

@@ -20,7 +20,7 @@
 //                      integer sums, one rounding shift by 22, saturation; border
 //                      pixels repeat) or the grey 128 outside the resized image;
 //                      writes the uint8 canvas and folds the per-image minimum and
-//                      maximum into two words with one atomic pair per wave.
+//                      maximum into two words (at most one atomic pair per block).
 //   to_input_kernel    a canvas byte can take 256 values, so the whole float64 /
 //                      float32 chain of the reference is evaluated once per value
 //                      and channel into a 768-entry table in LDS; then four pixels
@@ -114,10 +114,22 @@ letterbox_kernel(const PreBatch batch, int side, int tiles_x, uint8_t* __restric
         lo = min(lo, (unsigned int)__shfl_xor((int)lo, off));
         hi = max(hi, (unsigned int)__shfl_xor((int)hi, off));
     }
-    // both words start as all-ones: word 0 keeps the minimum, word 1 the minimum of 255 - value
+    // One update per block, and only when it would change the word: same-address
+    // atomics are served one at a time, and after the first few blocks of an image
+    // hardly any block still lowers either word.  Both words start as all-ones:
+    // word 0 keeps the minimum, word 1 the minimum of 255 - value.  The plain reads
+    // may be stale, which only costs an atomic that changes nothing.
+    __shared__ unsigned int part[2][4];
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&minmax[2 * blockIdx.y], lo);
-        atomicMin(&minmax[2 * blockIdx.y + 1], 255u - hi);
+        part[0][threadIdx.x >> 6] = lo;
+        part[1][threadIdx.x >> 6] = 255u - hi;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned int v = min(min(part[threadIdx.x][0], part[threadIdx.x][1]),
+                                   min(part[threadIdx.x][2], part[threadIdx.x][3]));
+        unsigned int* word = &minmax[2 * blockIdx.y + threadIdx.x];
+        if (v < __builtin_nontemporal_load(word)) atomicMin(word, v);
     }
 }
 
