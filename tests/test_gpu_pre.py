@@ -37,7 +37,8 @@ def test_flat_frame_gives_nan_under_min_max():
 
 
 SIZES = [(1920, 1080, 416), (640, 480, 416), (333, 500, 608), (100, 37, 320), (70, 50, 416),
-         (416, 416, 416), (417, 415, 416), (3, 2, 32), (1, 1, 32), (2000, 31, 416)]
+         (416, 416, 416), (417, 415, 416), (3, 2, 32), (1, 1, 32), (2000, 31, 416),
+         (4000, 3000, 416), (17, 4000, 416), (1919, 1081, 608), (5000, 700, 320)]
 
 
 @pytest.mark.parametrize("iw,ih,side", SIZES)

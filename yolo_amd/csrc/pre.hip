@@ -67,13 +67,76 @@ __device__ __forceinline__ int cubic_taps(int d, double scale, int w[4]) {
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// Source column (or row) the taps of destination index d are centred on.
+__device__ __forceinline__ int cubic_origin(int d, double scale) {
+    return (int)floorf((float)(((double)d + 0.5) * scale - 0.5));
+}
+
+constexpr int PATCH_BYTES = 40 * 1024 - 512;   // largest source footprint of a tile staged through LDS (4 blocks per CU)
+
+// Row sums of the four taps when they are 12 consecutive bytes held in three words.
+__device__ __forceinline__ void row_sums(const uint32_t q[3], const int wx[4], int hs[3]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int byte = 3 * k + c;
+            hs[c] += __mul24((int)((q[byte >> 2] >> (8 * (byte & 3))) & 255u), wx[k]);
+        }
+    }
+}
+
 // grid: (tiles of 32 x 8 canvas pixels, images of the chunk); block 256
+//
+// The bicubic gather is bound by the number of vector-memory instructions: every
+// lane has its own address, and such an instruction occupies the CU's address unit
+// for 16 to 27 cycles whatever its width.  So the source rectangle a tile needs
+// (the footprint of its 32 x 8 destination pixels plus the tap border) is first
+// copied to LDS with 16-byte loads, a whole wave reading consecutive chunks, and
+// the 48 taps of a pixel then come out of LDS.  A tile whose footprint does not fit
+// PATCH_BYTES (shrinking by more than about 6.5 x, where neighbouring pixels share
+// no taps anyway) gathers from global memory instead.  Products fit 24-bit
+// multiplies: bytes times weights (|w| < 2^12) in the row sums, row sums (< 2^21)
+// times weights.
 __global__ void __launch_bounds__(256)
 letterbox_kernel(const PreBatch batch, int side, int tiles_x, uint8_t* __restrict__ canvas,
                  unsigned int* __restrict__ minmax) {
+    __shared__ __align__(16) uint8_t patch[PATCH_BYTES + 32];
     const PreImage& im = batch.img[blockIdx.y];
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int cx = tx * 32 + (threadIdx.x & 31), cy = ty * 8 + (threadIdx.x >> 5);
+
+    // block-uniform: destination range of the tile inside the resized image and its
+    // source footprint [x_lo, x_hi] x [y_lo, y_hi]
+    const int dxa = max(tx * 32 - im.left, 0), dxb = min(tx * 32 + 31 - im.left, im.new_w - 1);
+    const int dya = max(ty * 8 - im.top, 0), dyb = min(ty * 8 + 7 - im.top, im.new_h - 1);
+    const bool any = dxa <= dxb && dya <= dyb;
+    int x_lo = 0, y_lo = 0, rowb = 0;
+    bool staged = false;
+    if (any) {
+        x_lo = clampi(cubic_origin(dxa, im.scale_x) - 1, 0, im.w - 1);
+        y_lo = clampi(cubic_origin(dya, im.scale_y) - 1, 0, im.h - 1);
+        const int x_hi = clampi(cubic_origin(dxb, im.scale_x) + 2, 0, im.w - 1);
+        const int y_hi = clampi(cubic_origin(dyb, im.scale_y) + 2, 0, im.h - 1);
+        const int nx = x_hi - x_lo + 1, ny = y_hi - y_lo + 1;
+        // a row's first byte sits 0..15 bytes into its first 16-byte chunk
+        rowb = (3 * nx + 15 + 15) & ~15;
+        staged = (long long)rowb * ny <= PATCH_BYTES;
+        if (staged) {
+            const int per_row = rowb >> 4;
+            for (int i = threadIdx.x; i < per_row * ny; i += 256) {
+                const int ry = i / per_row, j = i - ry * per_row;
+                const uint8_t* first = im.src + (long long)(y_lo + ry) * im.pitch + 3 * x_lo;
+                const uint8_t* chunk = first - ((uintptr_t)first & 15) + 16 * j;
+                // an aligned chunk that holds a byte of the row stays inside the row's
+                // memory page; one wholly behind the row's last needed byte is skipped
+                if (chunk < first + 3 * nx)
+                    *reinterpret_cast<uint4*>(patch + ry * rowb + 16 * j) = *reinterpret_cast<const uint4*>(chunk);
+            }
+        }
+    }
+    __syncthreads();
+
     unsigned int lo = 255u, hi = 0u;
     if (cx < side && cy < side) {
         int v[3] = {128, 128, 128};
@@ -85,18 +148,57 @@ letterbox_kernel(const PreBatch batch, int side, int tiles_x, uint8_t* __restric
             int xo[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) xo[k] = 3 * clampi(sx + k - 1, 0, im.w - 1);
+            // away from the left and right border the four taps of a row are 12
+            // consecutive bytes: fetched as the aligned words that cover them
+            const bool inner = sx >= 1 && sx + 2 <= im.w - 1;
             int acc[3] = {0, 0, 0};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint8_t* row = im.src + (long long)clampi(sy + r - 1, 0, im.h - 1) * im.pitch;
+                const int y = clampi(sy + r - 1, 0, im.h - 1);
+                const uint8_t* row = im.src + (long long)y * im.pitch;
                 int hs[3] = {0, 0, 0};
+                if (staged) {
+                    // offset of source byte 3 * x_lo of this row inside its LDS row
+                    const int lead = (int)(((uintptr_t)row + 3 * x_lo) & 15);
+                    const int base = (y - y_lo) * rowb + lead - 3 * x_lo;
+                    if (inner) {
+                        const int b = base + xo[0];
+                        const uint32_t* wp = reinterpret_cast<const uint32_t*>(patch + (b & ~3));
+                        const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[3];
+                        uint32_t q[3];
+                        q[0] = __builtin_amdgcn_alignbyte(d1, d0, b & 3);
+                        q[1] = __builtin_amdgcn_alignbyte(d2, d1, b & 3);
+                        q[2] = __builtin_amdgcn_alignbyte(d3, d2, b & 3);
+                        row_sums(q, wx, hs);
+                    } else {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                        for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) hs[c] += (int)row[xo[k] + c] * wx[k];
+                            for (int c = 0; c < 3; ++c) hs[c] += __mul24((int)patch[base + xo[k] + c], wx[k]);
+                        }
+                    }
+                } else if (inner) {
+                    // An aligned word that holds a byte of the row cannot leave the
+                    // row's memory page; the fourth word is only needed when the span
+                    // is unaligned and repeats the third otherwise.
+                    const uintptr_t addr = (uintptr_t)(row + xo[0]);
+                    const unsigned int shift = (unsigned int)(addr & 3);
+                    const uint32_t* wp = reinterpret_cast<const uint32_t*>(addr - shift);
+                    const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2], d3 = wp[shift ? 3 : 2];
+                    uint32_t q[3];
+                    q[0] = __builtin_amdgcn_alignbyte(d1, d0, shift);
+                    q[1] = __builtin_amdgcn_alignbyte(d2, d1, shift);
+                    q[2] = __builtin_amdgcn_alignbyte(d3, d2, shift);
+                    row_sums(q, wx, hs);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) hs[c] += __mul24((int)row[xo[k] + c], wx[k]);
+                    }
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) acc[c] += hs[c] * wy[r];
+                for (int c = 0; c < 3; ++c) acc[c] += __mul24(hs[c], wy[r]);
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) v[c] = clampi((acc[c] + (1 << 21)) >> 22, 0, 255);
