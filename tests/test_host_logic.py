@@ -183,3 +183,20 @@ def test_compute_ap():
         mpre[i - 1] = max(mpre[i - 1], mpre[i])
     idx = np.where(mrec[1:] != mrec[:-1])[0]
     assert compute_ap(rec, prec) == pytest.approx(np.sum((mrec[idx + 1] - mrec[idx]) * mpre[idx + 1]))
+
+
+def test_dropin_directory_resolves_the_reference_module_names():
+    """With dropin/ first on sys.path the reference callers' imports (`from utilis
+    import ...`, `from evaluate import get_map`, `from generate_anchors import
+    set_anchors_to_model`) land in this package."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r);"
+            "import utilis, evaluate, generate_anchors, yolo_v3;"
+            "print(evaluate.get_map.__module__, generate_anchors.kmeans.__module__,"
+            " utilis.filter_results.__module__, yolo_v3.yolo_v3.__module__)") % os.path.join(root, "dropin")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["yolo_amd.evaluate", "yolo_amd.generate_anchors",
+                                  "yolo_amd.utilis", "yolo_amd.yolo_v3"]
