@@ -38,4 +38,4 @@ def main(path, B=32, H=416):
     print("conv kernels total us", round(tot, 1), "gaps us", round(gaps, 1))
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], *[int(v) for v in sys.argv[2:4]])

@@ -604,6 +604,7 @@ struct Conv3Args {
     int leaky, dst_fp32;
     int tiles_y, tiles_x, ntiles;      // spatial tiles per image (y, x) and in the batch
     int tiles_n;                       // channel tiles
+    int prio;                          // raise the wave priority over the MFMA groups (about 1 %; YOLO_AMD_CONV3_PRIO=0 turns it off)
 };
 
 // WAVES = 4: wave cg owns all 11 pixel groups (three workgroups per CU).
@@ -724,6 +725,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 bf16x8 xf[6];
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
+                if (a.prio) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) {
                     if (NH == 2 && tp == 5 && ntp == 5) break;          // the second half has five groups
@@ -744,6 +746,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                         acc[tc][6 + tp] =
                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][6 + tp], 0, 0, 0);
             }
+            if (a.prio) __builtin_amdgcn_s_setprio(0);
             buf ^= 1;
             if (++kw == 3) { kw = 0; ++kh; }
         }
@@ -1467,6 +1470,7 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.C = d.c0; p.H = d.H; p.W = d.W; p.Cout = d.cout; p.K = K; p.leaky = d.leaky; p.dst_fp32 = d.dst_fp32;
         p.tiles_y = d.H / P3_TS; p.tiles_x = d.W / P3_TS; p.ntiles = d.B * p.tiles_y * p.tiles_x;
         p.tiles_n = d.cout_pad / 128;
+        p.prio = env_int("YOLO_AMD_CONV3_PRIO", 1);
         const int p3w = env_int("YOLO_AMD_CONV3_WAVES", p3_groups <= 1536 ? 8 : 4);
         if (p3w == 8)
             hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
