@@ -584,7 +584,8 @@ conv_igemm_kernel(const ConvArgs a) {
 //           double buffered, issued one per tap during the previous chunk.
 //   weights LDS-DMA ring of two (chunk, tap) stages = 128 channels x 32 k,
 //           XOR-swizzled rows as in conv_layout.h, counted vmcnt waits.
-// 48 KiB of LDS and <= 168 registers: three workgroups per CU.
+// 48 KiB of LDS and <= 168 registers: three workgroups per CU (four waves); the
+// eight-wave form takes 76 KiB, two workgroups per CU (see the LDS map in the kernel).
 // 13 divides every feature-map side of a 416-pixel input (13 * 2^n).
 constexpr int P3_TS = 13;                  // spatial tile side
 constexpr int P3_NPIX = P3_TS * P3_TS;     // 169 output pixels per tile
@@ -618,8 +619,17 @@ conv3x3_patch_kernel(const Conv3Args a) {
     constexpr int NTP = NH == 1 ? P3_TP : 6;       // pixel groups per wave (upper bound)
     constexpr int PP = 16 / WAVES;                 // patch LDS-DMA instructions per wave per chunk
     constexpr int WP = 8 / WAVES;                  // weight LDS-DMA instructions per wave per stage
-    __shared__ __attribute__((aligned(1024))) char lds[2 * P3_PATCH + 2 * P3_WSTAGE];
-    char* const wring = lds + 2 * P3_PATCH;
+    // LDS: weight ring, then the two patch buffers X and Y.  The eight-wave form adds
+    // 28 KiB behind Y: Y + that is where the residual tile (176 rows x 256 B = 44 KiB)
+    // is parked by LDS-DMA during the LAST chunk, which is made to read buffer X
+    // (chunks alternate X/Y counted from the end), so that the residual round trip to
+    // memory runs under the matrix work instead of after it.
+    constexpr bool RPRE = WAVES == 8;
+    constexpr int TILE_BYTES = 176 * 256;
+    __shared__ __attribute__((aligned(1024))) char lds_all[2 * P3_WSTAGE + 2 * P3_PATCH + (RPRE ? TILE_BYTES - P3_PATCH : 0)];
+    char* const wring = lds_all;
+    char* const lds = lds_all + 2 * P3_WSTAGE;                 // patch buffers
+    char* const rtile = RPRE ? lds + P3_PATCH : lds_all;       // epilogue tile (and parked residual)
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -650,6 +660,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
     }
     const int wfrag = (cg * 32) * 64 + slot_of<32>(r, q) * 16;
 
+    const int NCH = a.C / 32;
     // ---- patch fill: 16 LDS-DMA instructions of 4 rows each; this wave's are
     // rows 4i..4i+3 of plane cg for i = half*PP .. half*PP + PP - 1
     int poff[PP];
@@ -668,7 +679,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
         if constexpr (PP == 4) po = ii == 0 ? poff[0] : ii == 1 ? poff[1] : ii == 2 ? poff[2] : poff[3];
         else po = ii == 0 ? poff[0] : poff[1];
         const __bf16* pp = po >= 0 ? a.src + (po + chunk * 32) : a.zero;
-        lds_dma16(pp, lds + (chunk & 1) * P3_PATCH + cg * P3_PLANE + (half * PP + ii) * 1024);
+        lds_dma16(pp, lds + ((NCH - 1 - chunk) & 1) * P3_PATCH + cg * P3_PLANE + (half * PP + ii) * 1024);
     };
     // ---- weight fill: 8 LDS-DMA instructions per (chunk, tap) stage, WP per wave
     const int cout_pad = a.tiles_n * 128;
@@ -693,14 +704,15 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
         for (int tp = 0; tp < NTP; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int NCH = a.C / 32;
 #pragma unroll
     for (int ii = 0; ii < PP; ++ii) issue_patch(0, ii);
     issue_w(0, 0, 0);
     bool patch_behind = false;                 // a patch load was issued after the weights now awaited
+    // the vector epilogue will want the residual tile in LDS (all 128 channels of the tile exist)
+    const bool res_pre = RPRE && (a.prio & 2) && a.res && !a.dst_fp32 && (a.Cout & 7) == 0 && n0 + 128 <= a.Cout;
     int buf = 0;
     for (int chunk = 0; chunk < NCH; ++chunk) {
-        const char* pb = lds + (chunk & 1) * P3_PATCH;
+        const char* pb = lds + ((NCH - 1 - chunk) & 1) * P3_PATCH;
         const bool more_chunks = chunk + 1 < NCH;
         int kh = 0, kw = 0;
 #pragma unroll 1
@@ -715,6 +727,22 @@ conv3x3_patch_kernel(const Conv3Args a) {
             else if (more_chunks) issue_w(chunk + 1, 0, buf ^ 1);
             patch_behind = tap < PP && more_chunks;
             if (patch_behind) issue_patch(chunk + 1, tap);
+            if constexpr (RPRE) {
+                // last chunk: no patch to fetch any more; instruction w + 8 * tap of the
+                // 44 that park the residual tile goes out instead (one per wave and tap)
+                if (res_pre && !more_chunks && w + 8 * tap < TILE_BYTES / 1024) {
+                    const int j = w + 8 * tap;
+                    const int row = j * 4 + (lane >> 4);
+                    const int c = (lane & 15) ^ (row & 15);
+                    const __bf16* src = a.zero;
+                    if (row < P3_NPIX) {
+                        const int ty = row / P3_TS, tx = row - ty * P3_TS;
+                        src = a.res + (((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + n0 + c * 8;
+                    }
+                    lds_dma16(src, rtile + j * 1024);
+                    patch_behind = true;
+                }
+            }
 
             const int colb = ((r + kw + P3_TS * kh) & 15) * 16 + kh * 256;
             const char* ws = wring + buf * P3_WSTAGE + wfrag;
@@ -725,7 +753,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 bf16x8 xf[6];
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
-                if (a.prio) __builtin_amdgcn_s_setprio(2);
+                if (a.prio & 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) {
                     if (NH == 2 && tp == 5 && ntp == 5) break;          // the second half has five groups
@@ -746,7 +774,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                         acc[tc][6 + tp] =
                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][6 + tp], 0, 0, 0);
             }
-            if (a.prio) __builtin_amdgcn_s_setprio(0);
+            if (a.prio & 1) __builtin_amdgcn_s_setprio(0);
             buf ^= 1;
             if (++kw == 3) { kw = 0; ++kh; }
         }
@@ -761,9 +789,10 @@ conv3x3_patch_kernel(const Conv3Args a) {
             const int ty = slot / P3_TS, tx = slot - ty * P3_TS;
             return ((long long)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
         };
+        wait_vmcnt<0>();
         __syncthreads();
-        if (a.res) {
-            tile_load_residual<NSLOT, 128, 64 * WAVES>(lds, a.res, a.zero, a.Cout, n0, w, lane, pix);
+        if (a.res && !res_pre) {
+            tile_load_residual<NSLOT, 128, 64 * WAVES>(rtile, a.res, a.zero, a.Cout, n0, w, lane, pix);
             __syncthreads();
         }
 #pragma unroll
@@ -781,11 +810,11 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     if (a.leaky) x = x > 0.f ? x : 0.1f * x;
                     v[e] = x;
                 }
-                tile_put<128>(lds, slot, chl, v, a.res != nullptr);
+                tile_put<128>(rtile, slot, chl, v, a.res != nullptr);
             }
         }
         __syncthreads();
-        tile_store<NSLOT, 128, 64 * WAVES>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
+        tile_store<NSLOT, 128, 64 * WAVES>(rtile, (__bf16*)a.dst, a.Cout, n0, pix);
         return;
     }
 #pragma unroll
@@ -1470,7 +1499,7 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.C = d.c0; p.H = d.H; p.W = d.W; p.Cout = d.cout; p.K = K; p.leaky = d.leaky; p.dst_fp32 = d.dst_fp32;
         p.tiles_y = d.H / P3_TS; p.tiles_x = d.W / P3_TS; p.ntiles = d.B * p.tiles_y * p.tiles_x;
         p.tiles_n = d.cout_pad / 128;
-        p.prio = env_int("YOLO_AMD_CONV3_PRIO", 1);
+        p.prio = env_int("YOLO_AMD_CONV3_PRIO", 3);
         const int p3w = env_int("YOLO_AMD_CONV3_WAVES", p3_groups <= 1536 ? 8 : 4);
         if (p3w == 8)
             hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
