@@ -183,11 +183,28 @@ typedef struct {
     int fuse_next;        /* first layer only: run it together with the next    */
                           /* descriptor (3x3 stride-2, 32 -> 64 channels) as one */
                           /* launch; this layer's dst is then not written        */
+    /* Optional device scratch for a split reduction: at small batch a layer
+     * with few output tiles and a long K is cut into K slices whose fp32
+     * partial sums pass through this buffer (>= yolo_amd_conv_splitk_bytes,
+     * 16-byte aligned; layers of one stream may share it).  NULL: never split.
+     * The slices are added in a fixed order, so results are deterministic, but
+     * they differ in the last bits from the unsplit layer. */
+    void* splitk_ws;
+    size_t splitk_ws_bytes;
 } yolo_amd_conv_desc;
+
+/* Scratch bytes the split reduction of this layer wants (0: it would not be
+ * split).  Depends on the shape fields only. */
+size_t yolo_amd_conv_splitk_bytes(const yolo_amd_conv_desc* desc);
 
 /* Output channels are padded to a whole channel tile: returns the padded
  * count a weight/bias packer must allocate for `cout` real channels. */
 int yolo_amd_conv_cout_pad(int cout);
+
+/* The YOLO_AMD_* environment knobs (kernel variants for A/B timing,
+ * YOLO_AMD_SPLITK=0 to keep every reduction in one pass) are read once and
+ * cached; call this after changing the environment of a running process. */
+void yolo_amd_reload_knobs(void);
 
 /* Run `n` fused layers back to back on `stream`.  descs: host array.
  * zero_page: >= 256 bytes of device memory holding zeros (padding source). */

@@ -24,3 +24,15 @@ def pytest_collection_modifyitems(config, items):
 def golden():
     from helpers import load_golden
     return load_golden()
+
+
+@pytest.fixture(autouse=True)
+def _knobs_reread_after_each_test():
+    """The library caches the YOLO_AMD_* environment knobs.  This fixture is set up
+    before monkeypatch and therefore torn down after it has restored the
+    environment: the library then reads it again, so a knob set in one test never
+    leaks into the next."""
+    yield
+    mod = sys.modules.get("yolo_amd._lib")
+    if mod is not None and getattr(mod, "lib", None) is not None:
+        mod.lib.yolo_amd_reload_knobs()

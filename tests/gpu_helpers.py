@@ -14,6 +14,15 @@ import yolo_oracle as orc
 from yolo_amd.cfg import default_params, write_yolov3_cfg, yolov3_cfg_text
 
 
+def set_knob(monkeypatch, name, value):
+    """Set a YOLO_AMD_* development knob for the rest of the test: the library caches
+    the environment, so it is told to read it again (conftest does the same after
+    every test, once monkeypatch has restored the variable)."""
+    from yolo_amd._lib import lib
+    monkeypatch.setenv(name, value)
+    lib.yolo_amd_reload_knobs()
+
+
 def require_gpu():
     assert torch.cuda.is_available(), "GPU tests need a ROCm device (run with -m 'not gpu' on CPU)"
 
@@ -53,8 +62,11 @@ def oracle_forward(sd, H, C, A, x_np, return_layers=False):
     return orc.forward(sd, blocks, p, torch.from_numpy(x_np), return_layers=return_layers)
 
 
-def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None, fp32_out=False):
-    """One fused layer through yolo_amd_conv_forward.
+def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None, fp32_out=False,
+             splitk=False, info=None):
+    """One fused layer through yolo_amd_conv_forward.  splitk: lend the scratch the
+    library asks for, so a layer with few output tiles splits its reduction; info (a
+    dict) receives "splitk_bytes".
 
     x0: (B, H0, W0, c0) bf16 NHWC cuda; x1: optional (B, H, W, c1) bf16;
     w: (cout, cin, k, k) fp32 (already BN-folded); bias: (cout,) fp32.
@@ -89,6 +101,12 @@ def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None
     d[0].B, d[0].H, d[0].W = B, H, W
     d[0].cout, d[0].cout_pad, d[0].ksize, d[0].stride = cout, cout_pad, k, stride
     d[0].k_pad, d[0].leaky, d[0].dst_fp32, d[0].first_layer = K, int(leaky), int(fp32_out), 0
+    need = int(lib.yolo_amd_conv_splitk_bytes(d))
+    if info is not None:
+        info["splitk_bytes"] = need
+    if splitk and need:
+        ws = torch.full((need,), 0xFF, dtype=torch.uint8, device=dev)      # NaN-filled scratch
+        d[0].splitk_ws, d[0].splitk_ws_bytes = ws.data_ptr(), need
     check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), _lib.current_stream_ptr(dev)), "conv")
     torch.cuda.synchronize()
     return out

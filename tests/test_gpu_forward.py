@@ -21,6 +21,8 @@ import yolo_oracle as orc
 from helpers import assert_bit_equal, c_decode_head, c_filter_results, load_golden
 from yolo_amd.cfg import default_params
 
+from gpu_helpers import set_knob
+
 pytestmark = pytest.mark.gpu
 
 META, ARR = load_golden()
@@ -130,7 +132,7 @@ def test_thin_kernel_gives_the_im2col_kernels_bits(B, H, use_res, monkeypatch):
     if use_res:
         res = torch.from_numpy(r.standard_normal((B, H, H, 64)).astype(np.float32)).cuda().to(torch.bfloat16)
     thin = run_conv(x0, w, bias, leaky=True, residual=res)
-    monkeypatch.setenv("YOLO_AMD_THIN", "0")
+    set_knob(monkeypatch, "YOLO_AMD_THIN", "0")
     generic = run_conv(x0, w, bias, leaky=True, residual=res)
     assert torch.equal(thin.view(torch.int16), generic.view(torch.int16))
 
@@ -151,7 +153,7 @@ PATCH_CASES = [
 def test_conv3x3_patch_kernel(case, monkeypatch):
     from gpu_helpers import conv_reference, run_conv
     name, B, H, cin, cout, leaky, use_res, fp32_out = case
-    monkeypatch.setenv("YOLO_AMD_CONV3", "1")
+    set_knob(monkeypatch, "YOLO_AMD_CONV3", "1")
     r = gi.rs(abs(hash(name)) % 10000)
     x0 = torch.from_numpy(r.standard_normal((B, H, H, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
     w = torch.from_numpy((r.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
@@ -163,7 +165,7 @@ def test_conv3x3_patch_kernel(case, monkeypatch):
     want = conv_reference(x0, w, bias, leaky=leaky, residual=res)
     assert torch.isfinite(got).all(), "output holds NaN/inf (unwritten elements?)"
     # and the generic im2col kernel must agree with it
-    monkeypatch.setenv("YOLO_AMD_CONV3", "0")
+    set_knob(monkeypatch, "YOLO_AMD_CONV3", "0")
     generic = run_conv(x0, w, bias, leaky=leaky, residual=res, fp32_out=fp32_out).float().cpu()
     if fp32_out:
         torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
@@ -243,7 +245,7 @@ def test_forward_416_vs_oracle_and_end_to_end(conv3, monkeypatch):
     their two kernels (at batch 32 the large maps take the patch-reuse one by default)."""
     from gpu_helpers import build_model, oracle_forward
     from yolo_amd.utilis import filter_results
-    monkeypatch.setenv("YOLO_AMD_CONV3", conv3)
+    set_knob(monkeypatch, "YOLO_AMD_CONV3", conv3)
     model, params, sd = build_model(416)
     x_np = gi.images(9, 1, 416)
     det = model(torch.from_numpy(x_np).cuda())
@@ -263,15 +265,102 @@ def test_forward_416_vs_oracle_and_end_to_end(conv3, monkeypatch):
     print(f"416 e2e: HIP bf16 path keeps {out.shape[0]} rows, fp32 oracle path {ref_rows.shape[0]}")
 
 
-def test_batch_consistency_and_plan_reuse():
+def test_batch_consistency_and_plan_reuse(monkeypatch):
     from gpu_helpers import build_model
     model, params, _ = build_model(96)
     x = torch.from_numpy(gi.images(11, 4, 96)).cuda()
     full = model(x)
     again = model(x)
     assert torch.equal(full, again), "the forward pass is not deterministic"
+    # At such a small batch the deep layers split their reductions, into a number of
+    # slices that depends on the batch: the last bits may then differ between batch
+    # sizes, nothing more.
+    halves = torch.cat((model(x[:2]), model(x[2:])), 0)
+    rel = ((full - halves).abs() / (full.abs() + 1e-3)).flatten()
+    assert rel.median() < 2e-3 and rel.quantile(0.999) < 0.1
+    # With every reduction kept in one pass, per-image results are bit-identical
+    # whatever batch they are in.
+    set_knob(monkeypatch, "YOLO_AMD_SPLITK", "0")
+    model.refold()                                  # new plans
+    full = model(x)
     halves = torch.cat((model(x[:2]), model(x[2:])), 0)
     assert torch.equal(full, halves), "per-image results depend on the batch they are in"
+
+
+SPLITK_CASES = [
+    # name, B, H, c0, cout, k, stride, leaky, residual, fp32_out   (split needs >= 64 K-steps of 32)
+    ("k3_c512_n1024_13_res", 1, 13, 512, 1024, 3, 1, True, True, False),     # 144 K-steps, 32 tiles
+    ("k3_c256_n512_26_res", 1, 26, 256, 512, 3, 1, True, True, False),
+    ("k1_c2048_n512_13", 1, 13, 2048, 512, 1, 1, True, False, False),
+    ("k3s2_c256_n512_26", 2, 26, 256, 512, 3, 2, True, False, False),
+    ("head_c2048_n255_13", 1, 13, 2048, 255, 1, 1, False, False, True),      # fp32 out, odd channel count
+    ("k1_c2144_n128_ragged", 1, 15, 2144, 128, 1, 1, True, False, False),    # 67 K-steps: a short last slice, BK = 32
+    ("k3_c352_n64_bk32", 1, 13, 352, 64, 3, 1, True, True, False),           # 99 K-steps of 32, one-step ring
+]
+
+
+@pytest.mark.parametrize("case", SPLITK_CASES, ids=lambda c: c[0])
+def test_split_reduction_matches_the_reference_and_the_single_pass(case):
+    """Layers with few output tiles and a long K, with the scratch lent: the slices'
+    partial sums plus the finishing kernel must give what the fp32 reference gives,
+    to the single-pass tolerance, and stay within rounding of the single pass."""
+    from gpu_helpers import conv_reference, run_conv
+    name, B, H, c0, cout, k, stride, leaky, use_res, fp32_out = case
+    r = gi.rs(abs(hash(name)) % 10000)
+    x0 = torch.from_numpy(r.standard_normal((B, H, H, c0)).astype(np.float32)).cuda().to(torch.bfloat16)
+    w = torch.from_numpy((r.standard_normal((cout, c0, k, k)) * np.sqrt(2.0 / (c0 * k * k))).astype(np.float32))
+    bias = torch.from_numpy(r.normal(0, 0.3, cout).astype(np.float32))
+    Ho = (H + 2 * (k // 2) - k) // stride + 1
+    res = None
+    if use_res:
+        res = torch.from_numpy(r.standard_normal((B, Ho, Ho, cout)).astype(np.float32)).cuda().to(torch.bfloat16)
+    info = {}
+    split = run_conv(x0, w, bias, stride=stride, leaky=leaky, residual=res, fp32_out=fp32_out, splitk=True,
+                     info=info).float().cpu()
+    assert info["splitk_bytes"] > 0, "this shape was meant to be split"
+    single = run_conv(x0, w, bias, stride=stride, leaky=leaky, residual=res, fp32_out=fp32_out).float().cpu()
+    want = conv_reference(x0, w, bias, stride=stride, leaky=leaky, residual=res)
+    assert torch.isfinite(split).all(), "output holds NaN/inf (unwritten elements or scratch read before written)"
+    tol = 2e-4 if fp32_out else 1.0 / 128
+    torch.testing.assert_close(split, want, rtol=tol, atol=tol)
+    torch.testing.assert_close(split, single, rtol=tol, atol=tol)
+
+
+def test_large_batches_are_not_split():
+    from yolo_amd._lib import ConvDesc, lib
+    d = (ConvDesc * 1)()
+    d[0].c0, d[0].c1, d[0].B, d[0].H, d[0].W = 512, 0, 32, 13, 13
+    d[0].cout, d[0].cout_pad, d[0].ksize, d[0].stride, d[0].k_pad = 1024, 1024, 3, 1, 4608
+    assert lib.yolo_amd_conv_splitk_bytes(d) == 0
+    d[0].B = 1
+    assert lib.yolo_amd_conv_splitk_bytes(d) >= 2 * 169 * 1024 * 4
+
+
+def test_split_heads_decode_like_the_single_pass():
+    """Batch 1 at 416: the detection convolutions are split and the finishing kernel
+    decodes; the prediction must equal the unsplit plan's to fp32 rounding."""
+    from gpu_helpers import build_model
+    model, params, _ = build_model(416, C=80, seed=5)
+    x = torch.from_numpy(gi.images(13, 1, 416)).cuda()
+    with torch.no_grad():
+        split = model(x).clone()
+    assert model._plan(1, 416).splitk_bytes > 0
+    import os
+    os.environ["YOLO_AMD_SPLITK"] = "0"
+    try:
+        from yolo_amd._lib import lib
+        lib.yolo_amd_reload_knobs()
+        model.refold()
+        with torch.no_grad():
+            single = model(x)
+        assert model._plan(1, 416).splitk_bytes == 0
+    finally:
+        del os.environ["YOLO_AMD_SPLITK"]
+        lib.yolo_amd_reload_knobs()
+    # 75 layers of bf16 activations: a different summation order flips last bits
+    # (2^-8 relative each) here and there, and those differences travel on
+    rel = ((split - single).abs() / (single.abs() + 1e-3)).flatten()
+    assert rel.median() < 1e-2 and (split[..., 4] - single[..., 4]).abs().max() < 0.05
 
 
 def test_train_mode_falls_back_to_modules_with_a_warning():

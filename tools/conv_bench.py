@@ -87,6 +87,11 @@ def set_variant(v):
                     "am": "YOLO_AMD_CONV_AMUL", "bn": "YOLO_AMD_CONV_BN", "p3w": "YOLO_AMD_CONV3_WAVES", "prio": "YOLO_AMD_CONV3_PRIO"}[k]] = val
 
 
+def apply_variant(v):
+    set_variant(v)
+    lib.yolo_amd_reload_knobs()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
@@ -106,7 +111,7 @@ def main():
         times = {v: [] for v in variants}
         for rep in range(args.reps + 3):
             for v in variants:
-                set_variant(v)
+                apply_variant(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), stream), "conv")

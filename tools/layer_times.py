@@ -17,7 +17,15 @@ def main(path, B=32, H=416):
     if fused:                      # first two layers are one launch
         merged = dict(ops[1]); merged['stem'] = ops[0]
         ops = [merged] + ops[2:]
-    convs = [r for r in rows[idx:] if 'conv' in r['Kernel_Name']][:len(ops)]
+    # a split reduction is two launches: the finishing kernel's time is added to its layer's
+    convs = []
+    for r in rows[idx:]:
+        if 'splitk_finish' in r['Kernel_Name'] and convs:
+            convs[-1] = dict(convs[-1], End_Timestamp=r['End_Timestamp'], split=True)
+        elif 'conv' in r['Kernel_Name']:
+            if len(convs) == len(ops):
+                break
+            convs.append(dict(r))
     tot = 0; groups = {}
     prev_end = None; gaps = 0
     for op, r in zip(ops, convs):
@@ -30,11 +38,12 @@ def main(path, B=32, H=416):
             o0 = op['stem']; e0 = o0['ent']
             fl += 2 * B * o0['Ho'] * o0['Wo'] * e0['cout'] * e0['cin'] * e0['k'] ** 2
         key = (e['k'], e['stride'], e['cin'], e['cout'], op['Ho'])
+        key = key + (('split',) if r.get('split') else ())
         g = groups.setdefault(key, [0, 0.0, 0.0]); g[0] += 1; g[1] += dur; g[2] += fl
         tot += dur
-    print(f"{'k s cin cout Ho':26s} {'n':>3s} {'us each':>9s} {'us total':>9s} {'TF/s':>7s}")
+    print(f"{'k s cin cout Ho':34s} {'n':>3s} {'us each':>9s} {'us total':>9s} {'TF/s':>7s}")
     for key, (n, d, fl) in sorted(groups.items(), key=lambda kv: -kv[1][1]):
-        print(f"{str(key):26s} {n:3d} {d/n:9.1f} {d:9.1f} {fl/d/1e6:7.0f}")
+        print(f"{str(key):34s} {n:3d} {d/n:9.1f} {d:9.1f} {fl/d/1e6:7.0f}")
     print("conv kernels total us", round(tot, 1), "gaps us", round(gaps, 1))
 
 if __name__ == "__main__":

@@ -57,6 +57,8 @@ class ConvDesc(ctypes.Structure):
         ("decode_rows", ctypes.c_int),
         ("decode_anchors", ctypes.c_int),
         ("fuse_next", ctypes.c_int),
+        ("splitk_ws", ctypes.c_void_p),
+        ("splitk_ws_bytes", ctypes.c_size_t),
     ]
 
 
@@ -86,6 +88,8 @@ SYMBOLS = {
                                             ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                             ctypes.c_size_t, ctypes.c_void_p]),
+    "yolo_amd_reload_knobs": (None, []),
+    "yolo_amd_conv_splitk_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "yolo_amd_conv_cout_pad": (ctypes.c_int, [ctypes.c_int]),
     "yolo_amd_conv_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p]),

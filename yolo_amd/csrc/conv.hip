@@ -20,6 +20,7 @@
 // with no extra pass over memory.  Two LDS stages: the loads of K-tile t+1 are
 // in flight while the MFMAs of tile t run; one barrier per K-tile.
 #include <stdlib.h>
+#include <mutex>
 
 #include "common.h"
 #include "conv_layout.h"
@@ -52,6 +53,9 @@ struct ConvArgs {
     float dec_stride;
     float dec_aw[YOLO_AMD_MAX_ANCHORS], dec_ah[YOLO_AMD_MAX_ANCHORS];
     FastDiv divD;
+    // split K (small batches): workgroup (x, y) reduces K-steps [y*ksplit, (y+1)*ksplit)
+    // and writes raw fp32 sums to slice y of dst; conv_splitk_finish_kernel adds them up
+    int ksplit, kslices;
 };
 
 
@@ -255,8 +259,21 @@ conv_igemm_kernel(const ConvArgs a) {
         }
     }
 
+    // ---- K-steps of this workgroup: all of them, or one slice of a split reduction
+    int kt0 = 0, kt1 = a.Kpad / BK;
+    if (a.ksplit) {
+        kt0 = (int)blockIdx.y * a.ksplit;
+        kt1 = min(kt1, kt0 + a.ksplit);
+    }
     // ---- uniform K-tile walker: (tap, channel) of the current tile
     int k_c = 0, k_tap = 0, k_kh = 0, k_kw = 0;
+    if (kt0) {
+        const int k = kt0 * BK;
+        k_tap = k / Cin;
+        k_c = k - k_tap * Cin;
+        k_kh = k_tap / a.ksize;
+        k_kw = k_tap - k_kh * a.ksize;
+    }
     const int pad = a.ksize >> 1;
 
     // activation tile at the walker's position: uniform part, one LDS-DMA
@@ -325,7 +342,6 @@ conv_igemm_kernel(const ConvArgs a) {
     // multiplied, so PRE-1 whole stages stay in flight across each barrier.
     // The wait is counted (never vmcnt(0) in the steady state) and the barrier
     // is a bare s_barrier: a __syncthreads() here would drain the DMA queue.
-    const int KT = a.Kpad / BK;
     // hook(tc) runs after the MFMAs of channel group tc: the place to issue
     // loads one at a time between the matrix instructions
     auto multiply = [&](const char* sA, const char* sB, int ks_a, int ks_w, auto&& hook) {
@@ -353,12 +369,12 @@ conv_igemm_kernel(const ConvArgs a) {
         char* const ldsW = lds + 2 * A_BYTES;
         const int a_row = (wm * WMP) * (BKA * 2), w_row = (wn * WNC) * (BK * 2);
         stage_act(lds);
-        stage_wgt(ldsW, 0);
+        stage_wgt(ldsW, kt0);
         static_assert(NA % TC == 0 || TC % NA == 0, "activation loads spread evenly over the MFMA groups");
-        for (int kt = 0; kt < KT; kt += 2) {
-            char* const sA = lds + ((kt >> 1) & 1) * A_BYTES;
-            char* const sAn = lds + (((kt >> 1) & 1) ^ 1) * A_BYTES;
-            const bool more = kt + 2 < KT;
+        for (int kt = kt0; kt < kt1; kt += 2) {
+            char* const sA = lds + (((kt - kt0) >> 1) & 1) * A_BYTES;
+            char* const sAn = lds + ((((kt - kt0) >> 1) & 1) ^ 1) * A_BYTES;
+            const bool more = kt + 2 < kt1;
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -388,13 +404,13 @@ conv_igemm_kernel(const ConvArgs a) {
     } else {
 #pragma unroll
         for (int s = 0; s < PRE; ++s)
-            if (s < KT) stage(s, s);
+            if (kt0 + s < kt1) stage(s, kt0 + s);
         int cur = 0, nxt = PRE % NSTAGE;
-        for (int kt = 0; kt < KT; ++kt) {
-            wait_stages<PRE - 1, LPS>(min(PRE - 1, KT - 1 - kt));   // this wave's part of tile kt landed
+        for (int kt = kt0; kt < kt1; ++kt) {
+            wait_stages<PRE - 1, LPS>(min(PRE - 1, kt1 - 1 - kt));  // this wave's part of tile kt landed
             __builtin_amdgcn_s_barrier();                          // everyone's did; tile kt-1 fully read
             asm volatile("" ::: "memory");
-            if (kt + PRE < KT) stage(nxt, kt + PRE);
+            if (kt + PRE < kt1) stage(nxt, kt + PRE);
             const char* sA = lds + cur * STAGE + (wm * WMP) * (BK * 2);
             const char* sB = lds + cur * STAGE + A_BYTES + (wn * WNC) * (BK * 2);
 #pragma unroll
@@ -453,7 +469,8 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int tc = 0; tc < TC; ++tc)
                             if (tc == tc0 + t) v = acc[tc][tp];
-                        const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + c_lo + t * 16 + cq);
+                        f32x4 bs = f32x4{0.f, 0.f, 0.f, 0.f};     // partial sums of a split reduction stay raw
+                        if (!a.ksplit) bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + c_lo + t * 16 + cq);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float x = v[r] + bs[r];
@@ -474,7 +491,8 @@ conv_igemm_kernel(const ConvArgs a) {
                     d = ch - ai * a.dec_D;
                     anc = d == 2 ? a.dec_aw[ai] : a.dec_ah[ai];
                 }
-                float* const dstf = reinterpret_cast<float*>(a.dst);
+                float* const dstf = reinterpret_cast<float*>(a.dst) +
+                                    (a.ksplit ? (size_t)blockIdx.y * a.M * a.Cout : (size_t)0);
 #pragma unroll 4
                 for (int i = 0; i < BM / SUBS; ++i) {
                     const int slot = i * SUBS + sub;
@@ -1395,19 +1413,132 @@ conv3x3_thin_kernel(const ThinArgs a) {
 static int pick_bk(int c0, int c1) { return (c0 % 64 == 0 && c1 % 64 == 0) ? 64 : 32; }
 static int pick_bn(int cout) { return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128); }
 
+// ---------------------------------------------------------------- split K: the second half
+// At small batch the 13x13 and 26x26 layers have a handful of output tiles and a
+// reduction of up to 4608: a few workgroups walk 144 K-steps while most of the chip
+// idles.  Their K range is cut into slices (grid.y), every slice writes its raw fp32
+// sums, and this kernel adds the slices in ascending order and applies what the
+// single-pass epilogue applies: bias, LeakyReLU, residual, ONE rounding to bf16 --
+// or, for a detection convolution, the head decode into the prediction tensor.
+struct FinishArgs {
+    const float* partial;      // [slices][M][Cout]
+    const float* bias;
+    const __bf16* res;
+    void* dst;
+    int M, Cout, slices, leaky, dst_fp32;
+    int HoWo, Wo;
+    FastDiv divCout, divHoWo, divWo, divD;
+    int dec_D, dec_rows, dec_row_offset;
+    float dec_stride;
+    float dec_aw[YOLO_AMD_MAX_ANCHORS], dec_ah[YOLO_AMD_MAX_ANCHORS];
+};
+
+__global__ void __launch_bounds__(256)
+conv_splitk_finish_kernel(const FinishArgs a) {
+    const uint32_t total = (uint32_t)a.M * (uint32_t)a.Cout;
+    const uint32_t e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= total) return;
+    const uint32_t m = fdiv_u32(e, a.divCout);
+    const int ch = (int)(e - m * (uint32_t)a.Cout);
+    float x = a.partial[e];
+    for (int z = 1; z < a.slices; ++z) x += a.partial[(size_t)z * total + e];
+    x += a.bias[ch];
+    if (a.leaky) x = x > 0.f ? x : 0.1f * x;
+    if (a.dec_D) {
+        const uint32_t b = fdiv_u32(m, a.divHoWo);
+        const uint32_t pix = m - b * (uint32_t)a.HoWo;
+        const uint32_t oy = fdiv_u32(pix, a.divWo);
+        const float gx = (float)(int)(pix - oy * (uint32_t)a.Wo), gy = (float)(int)oy;
+        const int ai = (int)fdiv_u32((uint32_t)ch, a.divD);
+        const int d = ch - ai * a.dec_D;
+        const float anc = d == 2 ? a.dec_aw[ai] : a.dec_ah[ai];
+        const long long off = ((long long)b * a.dec_rows + a.dec_row_offset) * a.dec_D + (long long)pix * a.Cout;
+        reinterpret_cast<float*>(a.dst)[off + ch] = decode_value(x, d, gx, gy, anc, a.dec_stride);
+        return;
+    }
+    if (a.res) x += (float)a.res[e];
+    if (a.dst_fp32) reinterpret_cast<float*>(a.dst)[e] = x;
+    else reinterpret_cast<__bf16*>(a.dst)[e] = (__bf16)x;
+}
+
+// K-steps per slice and number of slices for a layer of `wgs` output tiles and KT
+// K-steps (of 32), or slices = 1: split only when the tiles alone leave most CUs
+// idle and the reduction is long enough to pay for the second launch (measured at
+// batch 1: a K-step costs a lone workgroup about 0.3 us, the finishing launch 7-8 us;
+// 3x3 layers on >= 256 channels gain 8-24 us each, 36-step layers and every 1x1 layer
+// lose), keep at least four steps per slice, an even number of them (the two-step
+// activation tile), and no more slices than fill the chip about twice.
+static void splitk_plan(long long wgs, int KT, int* steps, int* slices) {
+    *steps = KT; *slices = 1;
+    if (wgs > 128 || KT < 64) return;
+    int want = (int)std::min<long long>(16, std::max<long long>(1, 512 / wgs));
+    int len = (KT + want - 1) / want;
+    len = std::max(4, (len + 1) & ~1);
+    const int n = (KT + len - 1) / len;
+    if (n >= 2) { *steps = len; *slices = n; }
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int NSTAGE, int AMUL = 1>
 static void launch_igemm(ConvArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, NSTAGE, AMUL>), dim3(a.tiles_m * a.tiles_n),
-                       dim3(256), 0, stream, a);
+    if (a.kslices > 1) a.ksplit = a.ksplit * 32 / BK;          // planned in steps of 32
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, NSTAGE, AMUL>),
+                       dim3(a.tiles_m * a.tiles_n, a.kslices), dim3(256), 0, stream, a);
 }
 
 // Development knob: YOLO_AMD_CONV_NSTAGE / YOLO_AMD_CONV_BK override the ring
 // depth / K tile of the 128-channel-tile kernel so variants can be timed
 // against each other in one process (tools/conv_bench.py).
+// The environment is read once per knob (a forward pass makes several hundred
+// look-ups, which at batch 1 would cost as much host time as the launches);
+// yolo_amd_reload_knobs() makes the next look-ups read it again.
+struct KnobSlot {
+    const char* name;      // the call site's string literal
+    bool present;
+    int value;
+};
+static KnobSlot g_knobs[64];
+static int g_nknobs = 0;
+static std::mutex g_knob_mutex;
+
 static int env_int(const char* name, int dflt) {
+    std::lock_guard<std::mutex> lock(g_knob_mutex);
+    for (int i = 0; i < g_nknobs; ++i)
+        if (g_knobs[i].name == name) return g_knobs[i].present ? g_knobs[i].value : dflt;
     const char* v = getenv(name);
+    if (g_nknobs < 64) g_knobs[g_nknobs++] = KnobSlot{name, v != nullptr, v ? atoi(v) : 0};
     return v ? atoi(v) : dflt;
+}
+
+// Channel tile of the im2col kernel for a layer with M output pixels.
+static int choose_bn(const yolo_amd_conv_desc& d, long long M) {
+    int BN = pick_bn(d.cout);
+    // On the small feature maps 128x128 tiles give fewer than ~1.5 workgroups
+    // per CU; 64-channel tiles double the count (measured 5-8 % faster on the
+    // 13x13 layers).  YOLO_AMD_CONV_BN forces a narrower tile (development knob).
+    const long long groups128 = ((M + 127) / 128) * (d.cout_pad / 128);
+    int want_bn = env_int("YOLO_AMD_CONV_BN", 0);
+    if (want_bn == 0 && BN == 128 && groups128 < 384) want_bn = 64;
+    if ((want_bn == 32 || want_bn == 64) && want_bn < BN && d.cout_pad % want_bn == 0) BN = want_bn;
+    return BN;
+}
+
+static long long out_pixels(const yolo_amd_conv_desc& d) {
+    const int pad = d.ksize / 2;
+    const int Ho = (d.H + 2 * pad - d.ksize) / d.stride + 1;
+    const int Wo = (d.W + 2 * pad - d.ksize) / d.stride + 1;
+    return (long long)d.B * Ho * Wo;
+}
+
+// Slices the launcher would cut this layer's reduction into (1: no split).
+static void splitk_for(const yolo_amd_conv_desc& d, int* steps, int* slices) {
+    *steps = 0; *slices = 1;
+    if (d.first_layer || d.cout_pad <= 0 || (d.ksize != 1 && d.ksize != 3) || !env_int("YOLO_AMD_SPLITK", 1)) return;
+    const long long M = out_pixels(d);
+    if (M <= 0) return;
+    const int BN = choose_bn(d, M);
+    if (d.cout_pad % BN) return;
+    splitk_plan(((M + 127) / 128) * (d.cout_pad / BN), d.ksize * d.ksize * (d.c0 + d.c1) / 32, steps, slices);
 }
 
 static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream) {
@@ -1451,16 +1582,7 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     YA_REQUIRE(d.up0 == 0 || (d.up0 == 1 && d.ksize == 1 && d.H % 2 == 0 && d.W % 2 == 0),
                "conv: an upsampled source is supported for 1x1 convolutions only");
     int BK = pick_bk(d.c0, d.c1);
-    int BN = pick_bn(d.cout);
-    {
-        // On the small feature maps 128x128 tiles give fewer than ~1.5 workgroups
-        // per CU; 64-channel tiles double the count (measured 5-8 % faster on the
-        // 13x13 layers).  YOLO_AMD_CONV_BN forces a narrower tile (development knob).
-        const long long groups128 = ((M + 127) / 128) * (d.cout_pad / 128);
-        int want_bn = env_int("YOLO_AMD_CONV_BN", 0);
-        if (want_bn == 0 && BN == 128 && groups128 < 384) want_bn = 64;
-        if ((want_bn == 32 || want_bn == 64) && want_bn < BN && d.cout_pad % want_bn == 0) BN = want_bn;
-    }
+    const int BN = choose_bn(d, M);
     // K tile 32 keeps LDS at 32 KiB per workgroup (more resident workgroups);
     // 64 only pays for the widest inputs
     const int want_bk = env_int("YOLO_AMD_CONV_BK", (d.c0 + d.c1 >= 512) ? 64 : 32);
@@ -1542,11 +1664,40 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     // two-step activation tile (whole 128-byte lines per pixel): needs both
     // sources in whole 64-channel groups; not worth it for the shortest K loops
     const int amul = env_int("YOLO_AMD_CONV_AMUL", K >= 256 ? 2 : 1);
+
+    // Split reduction (see conv_splitk_finish_kernel): when the caller lent a
+    // workspace and the layer has too few output tiles to occupy the chip.
+    a.ksplit = 0; a.kslices = 1;
+    FinishArgs f{};
+    if (d.splitk_ws) {
+        int steps, slices;
+        splitk_for(d, &steps, &slices);
+        if (slices > 1 && (size_t)slices * (size_t)M * d.cout * sizeof(float) <= d.splitk_ws_bytes) {
+            YA_REQUIRE(((uintptr_t)d.splitk_ws & 15) == 0, "conv: split-K workspace must be 16-byte aligned");
+            f.partial = (const float*)d.splitk_ws; f.bias = a.bias; f.res = a.res; f.dst = a.dst;
+            f.M = a.M; f.Cout = a.Cout; f.slices = slices; f.leaky = a.leaky; f.dst_fp32 = a.dst_fp32;
+            f.HoWo = Ho * Wo; f.Wo = Wo;
+            f.divCout = make_fastdiv((uint32_t)a.Cout); f.divHoWo = a.divHoWo; f.divWo = a.divWo; f.divD = a.divD;
+            f.dec_D = a.dec_D; f.dec_rows = a.dec_rows; f.dec_row_offset = a.dec_row_offset;
+            f.dec_stride = a.dec_stride;
+            for (int i = 0; i < YOLO_AMD_MAX_ANCHORS; ++i) { f.dec_aw[i] = a.dec_aw[i]; f.dec_ah[i] = a.dec_ah[i]; }
+            a.ksplit = steps; a.kslices = slices;
+            a.dst = d.splitk_ws; a.dst_fp32 = 1; a.res = nullptr; a.leaky = 0; a.dec_D = 0;
+        }
+    }
+    auto finish = [&]() {
+        if (a.kslices > 1) {
+            const long long total = (long long)f.M * f.Cout;
+            hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                               stream, f);
+        }
+        return YA_OK;
+    };
     if (amul == 2 && BK == 32 && ns == 2 && d.c0 % 64 == 0 && d.c1 % 64 == 0) {
         if (BN == 128) launch_igemm<128, 128, 32, 2, 2, 2>(a, stream);
         else if (BN == 64) launch_igemm<128, 64, 32, 2, 2, 2>(a, stream);
         else launch_igemm<128, 32, 32, 4, 2, 2>(a, stream);
-        return YA_OK;
+        return finish();
     }
     if (BN == 128 && BK == 64) {
         if (ns == 3) launch_igemm<128, 128, 64, 2, 3>(a, stream);
@@ -1569,7 +1720,7 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     } else {
         launch_igemm<128, 32, 32, 4, 2>(a, stream);
     }
-    return YA_OK;
+    return finish();
 }
 
 }  // namespace yolo_amd
@@ -1580,6 +1731,19 @@ extern "C" int yolo_amd_conv_cout_pad(int cout) {
     if (cout <= 0) return 0;
     const int bn = pick_bn(cout);
     return (cout + bn - 1) / bn * bn;
+}
+
+extern "C" void yolo_amd_reload_knobs(void) {
+    std::lock_guard<std::mutex> lock(g_knob_mutex);
+    g_nknobs = 0;
+}
+
+extern "C" size_t yolo_amd_conv_splitk_bytes(const yolo_amd_conv_desc* d) {
+    if (!d) return 0;
+    int steps, slices;
+    splitk_for(*d, &steps, &slices);
+    if (slices <= 1) return 0;
+    return align_up((size_t)slices * (size_t)out_pixels(*d) * d->cout * sizeof(float), 256);
 }
 
 // descs[0] (first layer, fuse_next set) and descs[1] as one launch

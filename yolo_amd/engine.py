@@ -277,6 +277,17 @@ class Plan:
                     and e1["k"] == 3 and e1["stride"] == 2 and e1["cout"] == 64 and not o1["fp32"]):
                 self.descs[0].fuse_next = 1
                 self.fused_stem = True
+        # Scratch for split reductions: at small batch the deep layers have a few
+        # output tiles and K up to 4608; the library cuts such a K into slices when
+        # it is lent a buffer (one for all layers: they run in stream order).
+        need = max((lib.yolo_amd_conv_splitk_bytes(ctypes.byref(self.descs[j])) for j in range(len(ops))),
+                   default=0)
+        self.splitk_bytes = int(need)
+        if need:
+            self._splitk = torch.empty(need, dtype=torch.uint8, device=dev)
+            for j in range(len(ops)):
+                self.descs[j].splitk_ws = self._splitk.data_ptr()
+                self.descs[j].splitk_ws_bytes = need
         self.refold()
 
         # ---- decode descriptors
