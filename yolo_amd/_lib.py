@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolo_amd.so")
+# YOLO_AMD_LIB: another build of the same library, for A/B timing of kernel changes
+LIB_PATH = os.environ.get("YOLO_AMD_LIB") or os.path.join(_HERE, "libyolo_amd.so")
 
 MAX_HEADS = 4
 MAX_ANCHORS = 8

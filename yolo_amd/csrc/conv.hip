@@ -623,6 +623,8 @@ struct Conv3Args {
     int leaky, dst_fp32;
     int tiles_y, tiles_x, ntiles;      // spatial tiles per image (y, x) and in the batch
     int tiles_n;                       // channel tiles
+    long long* trace;                  // development aid (YOLO_AMD_CONV3_TRACE=<device address>): per workgroup
+                                       // four 100 MHz timestamps: start, K loop entered, K loop done, stores issued
     int prio;                          // raise the wave priority over the MFMA groups (about 1 %; YOLO_AMD_CONV3_PRIO=0 turns it off)
 };
 
@@ -651,6 +653,10 @@ conv3x3_patch_kernel(const Conv3Args a) {
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto stamp = [&](int i) {
+        if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 4 + i] = (long long)wall_clock64();
+    };
+    stamp(0);
     const int cg = w & 3, half = w >> 2;           // channel group (= patch plane), pixel-group half
     const int tp0 = half * 6;                      // first pixel group of this wave
     const int ntp = NH == 1 ? P3_TP : (half == 0 ? 6 : P3_TP - 6);
@@ -725,6 +731,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
     for (int ii = 0; ii < PP; ++ii) issue_patch(0, ii);
     issue_w(0, 0, 0);
+    stamp(1);
     bool patch_behind = false;                 // a patch load was issued after the weights now awaited
     // the vector epilogue will want the residual tile in LDS (all 128 channels of the tile exist)
     const bool res_pre = RPRE && (a.prio & 2) && a.res && !a.dst_fp32 && (a.Cout & 7) == 0 && n0 + 128 <= a.Cout;
@@ -799,6 +806,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
     }
 
     // ---- epilogue
+    stamp(2);
     const int cq = q * 4;
     if (!a.dst_fp32 && (a.Cout & 7) == 0) {
         constexpr int NSLOT = 176;
@@ -833,6 +841,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
         }
         __syncthreads();
         tile_store<NSLOT, 128, 64 * WAVES>(rtile, (__bf16*)a.dst, a.Cout, n0, pix);
+        stamp(3);
         return;
     }
 #pragma unroll
@@ -1499,6 +1508,7 @@ struct KnobSlot {
 };
 static KnobSlot g_knobs[64];
 static int g_nknobs = 0;
+static int g_knob_gen = 0;             // bumped by yolo_amd_reload_knobs()
 static std::mutex g_knob_mutex;
 
 static int env_int(const char* name, int dflt) {
@@ -1508,6 +1518,22 @@ static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     if (g_nknobs < 64) g_knobs[g_nknobs++] = KnobSlot{name, v != nullptr, v ? atoi(v) : 0};
     return v ? atoi(v) : dflt;
+}
+
+// a device address handed over in the environment (development aid); cached like the other knobs
+static void* env_ptr(const char* name) {
+    static std::mutex m;
+    static const char* cached_name = nullptr;
+    static void* cached = nullptr;
+    static int seen_gen = -1;
+    std::lock_guard<std::mutex> lock(m);
+    if (cached_name != name || seen_gen != g_knob_gen) {
+        const char* v = getenv(name);
+        cached = v ? (void*)strtoull(v, nullptr, 0) : nullptr;
+        cached_name = name;
+        seen_gen = g_knob_gen;
+    }
+    return cached;
 }
 
 // Channel tile of the im2col kernel for a layer with M output pixels.
@@ -1622,6 +1648,7 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.tiles_y = d.H / P3_TS; p.tiles_x = d.W / P3_TS; p.ntiles = d.B * p.tiles_y * p.tiles_x;
         p.tiles_n = d.cout_pad / 128;
         p.prio = env_int("YOLO_AMD_CONV3_PRIO", 3);
+        p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
         const int p3w = env_int("YOLO_AMD_CONV3_WAVES", p3_groups <= 1536 ? 8 : 4);
         if (p3w == 8)
             hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
@@ -1736,6 +1763,7 @@ extern "C" int yolo_amd_conv_cout_pad(int cout) {
 extern "C" void yolo_amd_reload_knobs(void) {
     std::lock_guard<std::mutex> lock(g_knob_mutex);
     g_nknobs = 0;
+    ++g_knob_gen;
 }
 
 extern "C" size_t yolo_amd_conv_splitk_bytes(const yolo_amd_conv_desc* d) {
