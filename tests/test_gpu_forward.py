@@ -149,11 +149,13 @@ PATCH_CASES = [
 ]
 
 
+@pytest.mark.parametrize("stg", ["1", "3"], ids=["tap-stages", "row-stages"])
 @pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: c[0])
-def test_conv3x3_patch_kernel(case, monkeypatch):
+def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     from gpu_helpers import conv_reference, run_conv
     name, B, H, cin, cout, leaky, use_res, fp32_out = case
     set_knob(monkeypatch, "YOLO_AMD_CONV3", "1")
+    set_knob(monkeypatch, "YOLO_AMD_CONV3_STG", stg)
     r = gi.rs(abs(hash(name)) % 10000)
     x0 = torch.from_numpy(r.standard_normal((B, H, H, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
     w = torch.from_numpy((r.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))

@@ -632,9 +632,12 @@ struct Conv3Args {
 // WAVES = 8: waves cg and cg + 4 split them 6 + 5, 48 accumulator registers each,
 // so that two workgroups per CU still give four waves per SIMD -- for the maps
 // whose 13x13 tiles number no more than two per CU.
-template <int WAVES>
+// STG = 3 (eight waves): a weight stage is a whole kernel row (three taps, 24 KiB; the ring
+// holds two) and the workgroup meets at a barrier once per row instead of once per tap.
+template <int WAVES, int STG = 1>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 3 : 4, WAVES == 4 ? 3 : 4)))
 conv3x3_patch_kernel(const Conv3Args a) {
+    static_assert(STG == 1 || (STG == 3 && WAVES == 8), "row-deep weight stages exist for the eight-wave form");
     constexpr int NH = WAVES / 4;                  // waves per channel group
     constexpr int NTP = NH == 1 ? P3_TP : 6;       // pixel groups per wave (upper bound)
     constexpr int PP = 16 / WAVES;                 // patch LDS-DMA instructions per wave per chunk
@@ -644,11 +647,13 @@ conv3x3_patch_kernel(const Conv3Args a) {
     // is parked by LDS-DMA during the LAST chunk, which is made to read buffer X
     // (chunks alternate X/Y counted from the end), so that the residual round trip to
     // memory runs under the matrix work instead of after it.
-    constexpr bool RPRE = WAVES == 8;
+    constexpr bool RPRE = WAVES == 8 && STG == 1;
     constexpr int TILE_BYTES = 176 * 256;
-    __shared__ __attribute__((aligned(1024))) char lds_all[2 * P3_WSTAGE + 2 * P3_PATCH + (RPRE ? TILE_BYTES - P3_PATCH : 0)];
+    constexpr int RING_BYTES = 2 * STG * P3_WSTAGE;            // two stages of STG taps
+    __shared__ __attribute__((aligned(1024))) char lds_all[RING_BYTES + 2 * P3_PATCH + (RPRE ? TILE_BYTES - P3_PATCH : 0)];
+    static_assert(sizeof(lds_all) >= TILE_BYTES, "the epilogue tile reuses this memory");
     char* const wring = lds_all;
-    char* const lds = lds_all + 2 * P3_WSTAGE;                 // patch buffers
+    char* const lds = lds_all + RING_BYTES;                    // patch buffers
     char* const rtile = RPRE ? lds + P3_PATCH : lds_all;       // epilogue tile (and parked residual)
 
     const int lane = threadIdx.x & 63;
@@ -736,6 +741,49 @@ conv3x3_patch_kernel(const Conv3Args a) {
     // the vector epilogue will want the residual tile in LDS (all 128 channels of the tile exist)
     const bool res_pre = RPRE && (a.prio & 2) && a.res && !a.dst_fp32 && (a.Cout & 7) == 0 && n0 + 128 <= a.Cout;
     int buf = 0;
+    if constexpr (STG == 3) {
+        // Ring slots 0-2 and 3-5 hold the three taps of the current and of the next
+        // kernel row.  At the row's barrier everything issued so far has landed (full
+        // wait); during the row each tap issues the matching tap of the next row into
+        // the other half, whose last readers passed this barrier.
+        issue_w(0, 1, 1);
+        issue_w(0, 2, 2);
+        int base = 0;
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const char* pb = lds + ((NCH - 1 - chunk) & 1) * P3_PATCH;
+            const bool more_chunks = chunk + 1 < NCH;
+#pragma unroll 1
+            for (int kh = 0; kh < 3; ++kh) {
+                wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const bool next_row = kh < 2 || more_chunks;
+                const int nchunk = kh < 2 ? chunk : chunk + 1, ntap0 = kh < 2 ? (kh + 1) * 3 : 0;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    if (next_row) issue_w(nchunk, ntap0 + kw, (base ^ 3) + kw);
+                    if (kh == 0 && kw < PP && more_chunks) issue_patch(chunk + 1, kw);
+                    const int colb = ((r + kw + P3_TS * kh) & 15) * 16 + kh * 256;
+                    const char* ws = wring + (base + kw) * P3_WSTAGE + wfrag;
+                    bf16x8 wf[2], xf[6];
+#pragma unroll
+                    for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
+#pragma unroll
+                    for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
+                    if (a.prio & 1) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                    for (int tp = 0; tp < 6; ++tp) {
+                        if (tp == 5 && ntp == 5) break;                 // the second half has five groups
+#pragma unroll
+                        for (int tc = 0; tc < 2; ++tc)
+                            acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+                    }
+                    if (a.prio & 1) __builtin_amdgcn_s_setprio(0);
+                }
+                base ^= 3;
+            }
+        }
+    } else
     for (int chunk = 0; chunk < NCH; ++chunk) {
         const char* pb = lds + ((NCH - 1 - chunk) & 1) * P3_PATCH;
         const bool more_chunks = chunk + 1 < NCH;
@@ -1650,7 +1698,9 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.prio = env_int("YOLO_AMD_CONV3_PRIO", 3);
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
         const int p3w = env_int("YOLO_AMD_CONV3_WAVES", p3_groups <= 1536 ? 8 : 4);
-        if (p3w == 8)
+        if (p3w == 8 && env_int("YOLO_AMD_CONV3_STG", 3) == 3)
+            hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (p3w == 8)
             hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else
             hipLaunchKernelGGL(conv3x3_patch_kernel<4>, dim3(p.ntiles * p.tiles_n), dim3(256), 0, stream, p);
