@@ -1698,7 +1698,8 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.prio = env_int("YOLO_AMD_CONV3_PRIO", 3);
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
         const int p3w = env_int("YOLO_AMD_CONV3_WAVES", p3_groups <= 1536 ? 8 : 4);
-        if (p3w == 8 && env_int("YOLO_AMD_CONV3_STG", 3) == 3)
+        const int stg = env_int("YOLO_AMD_CONV3_STG", 3);
+        if (p3w == 8 && stg == 3)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (p3w == 8)
             hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
