@@ -1680,15 +1680,17 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         return YA_OK;
     }
     // Stride-1 3x3 layers on 13*2^n feature maps can take the patch-reuse kernel.
-    // Measured at batch 32 (tools/conv_bench.py): with two to six 13x13 tiles per
-    // CU (52x52 and 26x26 maps) its eight-wave form wins, with more (104x104) the
-    // four-wave form, with one tile per CU (13x13 maps) the 128-pixel tiles of the
-    // im2col kernel fill the GPU as well.  YOLO_AMD_CONV3=0/1 and
+    // Measured at batch 32 (tools/conv_bench.py): its eight-wave form with row-deep
+    // weight stages wins on every map from 13x13 (one workgroup per CU: 59.5 us
+    // against 75.3 us for the im2col kernel) to 104x104 (76.9 against 79.5 us for the
+    // four-wave form); below one workgroup per CU the im2col kernel's smaller tiles
+    // fill the chip better.  With tap-deep stages (YOLO_AMD_CONV3_STG=1) the four-wave
+    // form takes the layers with more than six tiles per CU.  YOLO_AMD_CONV3=0/1 and
     // YOLO_AMD_CONV3_WAVES=4/8 force the choice (development knobs).
     const long long p3_groups = (long long)d.B * (d.H / P3_TS) * (d.W / P3_TS) * (d.cout_pad / 128);
     const int p3 = env_int("YOLO_AMD_CONV3", -1);
     if (d.ksize == 3 && d.stride == 1 && d.c1 == 0 && d.up0 == 0 && d.H % P3_TS == 0 && d.W % P3_TS == 0 &&
-        d.cout_pad % 128 == 0 && (p3 == 1 || (p3 < 0 && p3_groups >= 500))) {
+        d.cout_pad % 128 == 0 && (p3 == 1 || (p3 < 0 && p3_groups >= 256))) {
         Conv3Args p;
         p.src = (const __bf16*)d.src0; p.wgt = (const __bf16*)d.weight; p.bias = d.bias;
         p.res = (const __bf16*)d.residual; p.dst = d.dst; p.zero = (const __bf16*)zero_page;
@@ -1697,8 +1699,8 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.tiles_n = d.cout_pad / 128;
         p.prio = env_int("YOLO_AMD_CONV3_PRIO", 3);
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
-        const int p3w = env_int("YOLO_AMD_CONV3_WAVES", p3_groups <= 1536 ? 8 : 4);
         const int stg = env_int("YOLO_AMD_CONV3_STG", 3);
+        const int p3w = env_int("YOLO_AMD_CONV3_WAVES", (stg == 3 || p3_groups <= 1536) ? 8 : 4);
         if (p3w == 8 && stg == 3)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (p3w == 8)
