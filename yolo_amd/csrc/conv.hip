@@ -1683,14 +1683,16 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     // Measured at batch 32 (tools/conv_bench.py): its eight-wave form with row-deep
     // weight stages wins on every map from 13x13 (one workgroup per CU: 59.5 us
     // against 75.3 us for the im2col kernel) to 104x104 (76.9 against 79.5 us for the
-    // four-wave form); below one workgroup per CU the im2col kernel's smaller tiles
-    // fill the chip better.  With tap-deep stages (YOLO_AMD_CONV3_STG=1) the four-wave
+    // four-wave form); it keeps winning down to about one workgroup per two CUs
+    // (batch 4-8 at 416: 2-4 % on the whole forward pass), below that the im2col
+    // kernel's smaller tiles and its split reductions fill the chip better
+    // (YOLO_AMD_CONV3_MIN moves the threshold).  With tap-deep stages (YOLO_AMD_CONV3_STG=1) the four-wave
     // form takes the layers with more than six tiles per CU.  YOLO_AMD_CONV3=0/1 and
     // YOLO_AMD_CONV3_WAVES=4/8 force the choice (development knobs).
     const long long p3_groups = (long long)d.B * (d.H / P3_TS) * (d.W / P3_TS) * (d.cout_pad / 128);
     const int p3 = env_int("YOLO_AMD_CONV3", -1);
     if (d.ksize == 3 && d.stride == 1 && d.c1 == 0 && d.up0 == 0 && d.H % P3_TS == 0 && d.W % P3_TS == 0 &&
-        d.cout_pad % 128 == 0 && (p3 == 1 || (p3 < 0 && p3_groups >= 256))) {
+        d.cout_pad % 128 == 0 && (p3 == 1 || (p3 < 0 && p3_groups >= env_int("YOLO_AMD_CONV3_MIN", 128)))) {
         Conv3Args p;
         p.src = (const __bf16*)d.src0; p.wgt = (const __bf16*)d.weight; p.bias = d.bias;
         p.res = (const __bf16*)d.residual; p.dst = d.dst; p.zero = (const __bf16*)zero_page;
