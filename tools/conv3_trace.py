@@ -39,13 +39,34 @@ def main():
     torch.cuda.synchronize()
     del os.environ["YOLO_AMD_CONV3_TRACE"]
     lib.yolo_amd_reload_knobs()
-    t = trace.cpu().numpy().reshape(-1, 4)
-    t = t[t[:, 0] > 0].astype(np.float64) / 100.0          # microseconds
+    raw = trace.cpu().numpy().reshape(-1, 8)
+    raw = raw[raw[:, 0] > 0]
+    t = raw[:, :4].astype(np.float64) / 100.0               # microseconds
     t0 = t[:, 0].min()
     t -= t0
     n = t.shape[0]
     print(f"{a.layer}, batch {a.batch}: {n} workgroups, kernel {e0.elapsed_time(e1) * 1e3:.1f} us by events, "
           f"{t[:, 3].max():.1f} us first start -> last stores issued")
+    full = trace.cpu().numpy().reshape(-1, 8)
+    idx = np.nonzero(full[:, 0] > 0)[0]
+    kloop = t[:, 2] - t[:, 1]
+    print("  K loop by blockIdx % 8 (workgroups that share an XCD):",
+          " ".join(f"{kloop[idx % 8 == x].mean():.1f}" for x in range(8)))
+    print("  K loop by launch order, eighths of the grid:",
+          " ".join(f"{kloop[(idx * 8) // (idx.max() + 1) == e].mean():.1f}" for e in range(8)))
+    print("  K loop by start time, quartiles of the first 512:",
+          " ".join(f"{q:.1f}" for q in np.quantile(kloop[np.argsort(t[:, 0])[:512]], [0, 0.25, 0.5, 0.75, 1])))
+    # which workgroups share a CU: XCC_ID (high word) and, in HW_ID, CU_ID bits 11:8, SH bit 12, SE bits 15:13
+    hw = raw[:, 4]
+    cu_key = ((hw >> 32) << 16) | (hw & 0xFF00)
+    keys, inv, counts = np.unique(cu_key, return_inverse=True, return_counts=True)
+    print(f"  {len(keys)} distinct (XCC, SE, SH, CU) places; workgroups per place: min {counts.min()} max {counts.max()}")
+    first_on_cu = np.zeros(len(t), dtype=bool)
+    for k in range(len(keys)):
+        members = np.nonzero(inv == k)[0]
+        first_on_cu[members[np.argmin(t[members, 0])]] = True
+    print(f"  K loop of the workgroup that started first on its CU: {kloop[first_on_cu].mean():.1f}, of the others: "
+          f"{kloop[~first_on_cu].mean():.1f}")
     order = np.argsort(t[:, 0])
     first_round = t[order[: min(n, 512)]]
     later = t[order[512:]] if n > 512 else None

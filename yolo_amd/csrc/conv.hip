@@ -624,7 +624,7 @@ struct Conv3Args {
     int tiles_y, tiles_x, ntiles;      // spatial tiles per image (y, x) and in the batch
     int tiles_n;                       // channel tiles
     long long* trace;                  // development aid (YOLO_AMD_CONV3_TRACE=<device address>): per workgroup
-                                       // four 100 MHz timestamps: start, K loop entered, K loop done, stores issued
+                                       // eight words: 100 MHz timestamps (start, K loop entered, K loop done, stores issued), XCC_ID << 32 | HW_ID
     int prio;                          // raise the wave priority over the MFMA groups (about 1 %; YOLO_AMD_CONV3_PRIO=0 turns it off)
 };
 
@@ -659,9 +659,12 @@ conv3x3_patch_kernel(const Conv3Args a) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     auto stamp = [&](int i) {
-        if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 4 + i] = (long long)wall_clock64();
+        if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + i] = (long long)wall_clock64();
     };
     stamp(0);
+    if (a.trace && threadIdx.x == 0)       // where it runs: HW_ID (CU, SE, ...) and XCC_ID
+        a.trace[(size_t)blockIdx.x * 8 + 4] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                              (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     const int cg = w & 3, half = w >> 2;           // channel group (= patch plane), pixel-group half
     const int tp0 = half * 6;                      // first pixel group of this wave
     const int ntp = NH == 1 ? P3_TP : (half == 0 ? 6 : P3_TP - 6);
