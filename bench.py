@@ -15,13 +15,23 @@ exchange a caller such as an mAP evaluation needs afterwards, is exercised once
 after the timed region.)
 
 Rank 0 prints ONE JSON line.  Beside the required fields it carries
-  roofline      conv stack (the dominant kernel family) against the dense bf16
-                MFMA peak, from HIP events recorded on the launch stream
-                inside the timed steps
+  roofline      the dominant kernel (the patch-reuse 3x3 convolution, half of the
+                step's GPU time) against the dense bf16 MFMA peak: algorithmic FLOPs
+                of its launches / their duration, from HIP events recorded on the
+                launch stream around every conv launch of extra passes that follow
+                the timed region; `traffic` = HBM-side bytes per launch of that
+                kernel from two rocprofv3 --pmc passes over this same script, run as
+                child processes before this process touches the GPU (N = 1 only)
+  roofline_stack the whole conv stack (74 launches) the same way, its time taken
+                from HIP events inside the timed steps
+  conv_kernels  per kernel family: launches, time, TFLOP/s (same event passes)
   cpu_baseline  the CPU port of the same path (torch CPU fp32 forward + the
                 reference-shaped Python-loop NMS) on a bounded sample, rank 0,
                 N = 1 only
-  stages_ms     per-step time of conv stack / decode / NMS
+  stages_ms     per-step time of the conv stack (head decode fused into the
+                detection convolutions) and of the NMS
+  nms           us per image and achieved GB/s on the algorithmic bytes (the
+                prediction tensor read once, B*N*D*4)
   pipelined     (N = 1) the same K batches through yolo_amd.harness.DetectionPipeline:
                 NMS of batch i on a second HIP stream beside the forward pass of
                 batch i+1; reported beside `value`, which stays the plain two-call loop
@@ -101,6 +111,114 @@ def cpu_baseline(sd, H, C, A, conf, nms, budget_s=20.0, max_images=4):
                       f"forward {1e3 * t_fwd / done:.0f} ms/img, NMS {1e3 * t_nms / done:.0f} ms/img"}
 
 
+def measure_traffic(argv_tail, steps=3, warmup=1, timeout_s=240):
+    """HBM-side bytes of the conv kernels from rocprofv3 PMC passes over this script
+    (reads and writes in separate passes: the TCC block holds four counters).  Run as
+    child processes, each with a time limit, before the parent initialises the GPU.
+    Returns (per-kernel-family dict, None) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="yolo_amd_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    tot = collections.defaultdict(lambda: collections.defaultdict(float))
+    launches = collections.defaultdict(int)
+    try:
+        for name, counters in (("rd", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum"]),
+                               ("wr", ["TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"])):
+            cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(tmp, name), "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup),
+                   "--no-cpu-baseline", "--no-pipelined", "--no-traffic", "--no-kernel-pass", *argv_tail]
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                    start_new_session=True)
+            try:
+                _, err = proc.communicate(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                proc.wait()
+                return None, f"rocprofv3 pass {name} exceeded {timeout_s} s"
+            if proc.returncode != 0:
+                return None, f"rocprofv3 pass {name} failed ({proc.returncode}): {err.decode(errors='replace')[-200:]}"
+            for f in glob.glob(os.path.join(tmp, name, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        kn = r["Kernel_Name"]
+                        if "yolo_amd::conv" not in kn:
+                            continue
+                        fam = kn.split("(")[0].replace("void ", "").replace("yolo_amd::", "")
+                        tot[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+                        if r["Counter_Name"] == counters[0] and name == "rd":
+                            launches[fam] += 1
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for fam, c in tot.items():
+        rd, rd32 = c["TCC_EA0_RDREQ_sum"], c["TCC_EA0_RDREQ_32B_sum"]
+        wr, wr64 = c["TCC_EA0_WRREQ_sum"], c["TCC_EA0_WRREQ_64B_sum"]
+        # gfx950 tallies the 128-byte requests of 16-byte-per-lane loads once: 128 B per
+        # non-32B read request; writes are 64 B or 32 B per request
+        n = max(launches[fam], 1)
+        out[fam] = {"launches_profiled": launches[fam],
+                    "read_bytes_per_launch": ((rd - rd32) * 128 + rd32 * 32) / n,
+                    "write_bytes_per_launch": (wr64 * 64 + (wr - wr64) * 32) / n}
+    if not out:
+        return None, "no conv kernel in the counter files"
+    return out, None
+
+
+KERNEL_FAMILY = {"patch": "conv3x3_patch_kernel", "stem": "conv_stem_kernel", "thin": "conv3x3_thin_kernel",
+                 "first": "conv_first_kernel"}
+
+
+def kernel_pass(plan, passes):
+    """HIP events around every conv launch (on the stream the kernels run on), `passes`
+    times over the whole stack, on the data the last step left in the arena.  Returns
+    {family: {"launches", "ms", "flops"}}, averaged over the passes."""
+    import ctypes
+    from yolo_amd import _lib
+    from yolo_amd._lib import check, lib
+    groups = []                                   # (first desc, count, family, flops)
+    j = 0
+    while j < len(plan.ops):
+        n = 2 if plan.descs[j].first_layer and plan.descs[j].fuse_next else 1
+        ch = _lib.conv_choice(plan.descs[j])
+        fam = KERNEL_FAMILY.get(ch["kernel"]) or \
+            f"conv_igemm_kernel<{ch['bm']}, {ch['bn']}, {ch['bk']}, act {ch['act_ksteps']}>"
+        fl = sum(2.0 * plan.B * o["Ho"] * o["Wo"] * o["ent"]["cout"] * o["ent"]["cin"] * o["ent"]["k"] ** 2
+                 for o in plan.ops[j:j + n])
+        groups.append((j, n, fam, fl))
+        j += n
+    stream = _lib.current_stream_ptr(plan.device)
+    size = ctypes.sizeof(_lib.ConvDesc)
+    base = ctypes.addressof(plan.descs)
+    acc = {}
+    for _ in range(passes):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(groups) + 1)]
+        evs[0].record()
+        for g, (j0, n, fam, fl) in enumerate(groups):
+            ptr = ctypes.cast(base + j0 * size, ctypes.POINTER(_lib.ConvDesc))
+            check(lib.yolo_amd_conv_forward(ptr, n, plan.zero_page.data_ptr(), stream), "conv_forward")
+            evs[g + 1].record()
+        torch.cuda.synchronize()
+        for g, (j0, n, fam, fl) in enumerate(groups):
+            a = acc.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            a["launches"] += 1
+            a["ms"] += evs[g].elapsed_time(evs[g + 1])
+            a["flops"] += fl
+    for a in acc.values():
+        a["launches"] //= passes
+        a["ms"] /= passes
+        a["flops"] /= passes
+    return acc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,11 +230,20 @@ def main():
     ap.add_argument("--nms", type=float, default=0.4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra pipelined measurement")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes")
+    ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-launch event passes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # PMC passes first: they run as child processes and must be over before this
+    # process initialises the GPU
+    traffic, traffic_note = None, "not measured"
+    if world == 1 and rank == 0 and not args.no_traffic:
+        tail = ["--height", str(args.height), "--batch", str(args.batch), "--conf", str(args.conf),
+                "--nms", str(args.nms)]
+        traffic, traffic_note = measure_traffic(tail)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -173,10 +300,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    conv_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in plan.stage_events]))
-    dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in plan.stage_events]))
+    conv_ms = float(np.mean([e[0].elapsed_time(e[2]) for e in plan.stage_events]))
     nms_ms = float(np.mean([a.elapsed_time(b) for a, b in nms_events]))
     plan.stage_events = None
+    kernels = None
+    if rank == 0 and not args.no_kernel_pass:
+        kernels = kernel_pass(plan, max(3, min(args.steps, 10)))
     n_rows = 0 if isinstance(out, int) else int(out.shape[0])
     if distributed:
         # outside the timed region: the rows of all ranks in single-process order
@@ -208,17 +337,43 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
         achieved = flops_per_batch / (conv_ms * 1e-3) / 1e12
-        # HBM-side bytes of the conv stack from the PMC passes of tools/pmc_bench.sh over this
-        # same command (the profiler cannot run inside the timed region); null when the file is
-        # absent or was taken for another batch size
-        traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "round1_conv_traffic.json")
-        if os.path.exists(tpath) and (B, H) == (32, 416):
-            with open(tpath) as fh:
-                traffic = round(json.load(fh)["hbm_bytes_per_launch"])
-            traffic_src = "profiles/round1_conv_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per conv launch)"
         n_convs = len(plan.ops) - (1 if getattr(plan, "fused_stem", False) else 0)
         N = plan.N
+        stack = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                 "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),
+                 "kernel": f"conv stack ({n_convs} fused conv launches per step, head decode included)",
+                 "flop_per_launch_avg": flops_per_batch / n_convs, "avg_launch_ms": round(conv_ms / n_convs, 5),
+                 "traffic": None}
+        if traffic:
+            n_prof = max(1, sum(t["launches_profiled"] for t in traffic.values()))
+            stack["traffic"] = round(sum((t["read_bytes_per_launch"] + t["write_bytes_per_launch"]) *
+                                         t["launches_profiled"] for t in traffic.values()) / n_prof)
+        roofline, conv_kernels = dict(stack), None
+        if kernels:
+            conv_kernels = {}
+            for fam, a in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
+                conv_kernels[fam] = {"launches_per_step": a["launches"], "ms_per_step": round(a["ms"], 4),
+                                     "avg_launch_ms": round(a["ms"] / a["launches"], 5),
+                                     "tflops": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 1)}
+            dom, a = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+            ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            tr = None
+            if traffic and "<" not in dom:         # (the im2col instantiations share one name stem)
+                tkey = next((k for k in traffic if k.startswith(dom)), None)
+                if tkey:
+                    tr = round(traffic[tkey]["read_bytes_per_launch"] + traffic[tkey]["write_bytes_per_launch"])
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": tr,
+                        "kernel": f"{dom} ({a['launches']} launches per step, "
+                                  f"{100 * a['ms'] / sum(k['ms'] for k in kernels.values()):.0f} % of the conv time)",
+                        "flop_per_launch_avg": a["flops"] / a["launches"],
+                        "avg_launch_ms": round(a["ms"] / a["launches"], 5),
+                        "how": "HIP events around every conv launch, on the launch stream, in extra passes "
+                               "after the timed region"}
+        roofline["traffic_note"] = traffic_note if not traffic else \
+            "rocprofv3 --pmc TCC_EA0_RDREQ/_32B and TCC_EA0_WRREQ/_64B, two child passes over this script; " \
+            "128 B per non-32B read request, 64/32 B per write request; bytes per launch of this kernel"
+        pred_bytes = float(B) * N * (5 + C) * 4
         result = {
             "metric": "images/sec (node) YOLOv3-416 end-to-end incl. NMS",
             "value": round(value, 2), "unit": "images/sec",
@@ -229,19 +384,20 @@ def main():
                                    f"NMS {args.nms}, seeded synthetic weights and images",
                        "global_batch": world * B, "height": H, "boxes_per_image": N,
                        "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2),
-                         "peak": MFMA_BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "kernel": f"conv stack ({n_convs} fused conv launches per step)",
-                         "flop_per_launch_avg": flops_per_batch / n_convs,
-                         "avg_launch_ms": round(conv_ms / n_convs, 5)},
-            "stages_ms": {"conv_stack": round(conv_ms, 4), "decode": round(dec_ms, 4),
-                          "nms": round(nms_ms, 4)},
+            "roofline": roofline,
+            "roofline_stack": stack,
+            "stages_ms": {"conv_stack": round(conv_ms, 4), "nms": round(nms_ms, 4)},
+            "nms": {"us_per_img": round(1e3 * nms_ms / B, 3),
+                    "achieved_gbs": round(pred_bytes / (nms_ms * 1e-3) / 1e9, 1), "peak_gbs": HBM_PEAK_GBS,
+                    "frac": round(pred_bytes / (nms_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "bytes": "the (B, N, 5+C) fp32 prediction read once"},
             "nms_us_per_img": round(1e3 * nms_ms / B, 3),
-            "decode_gbs": round(2.0 * B * N * (5 + C) * 4 / (dec_ms * 1e-3) / 1e9, 1),
             "detections_last_step": n_rows,
         }
+        if conv_kernels:
+            result["conv_kernels"] = conv_kernels
+        if traffic:
+            result["hbm_traffic_per_launch"] = {k: {kk: round(vv) for kk, vv in v.items()} for k, v in traffic.items()}
         if pipelined:
             result["pipelined"] = pipelined
         if world == 1 and not args.no_cpu_baseline:

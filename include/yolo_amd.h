@@ -11,8 +11,11 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all
  *     work is enqueued asynchronously on it and nothing synchronises;
  *   - the caller allocates every buffer, including worst-case outputs and the
- *     workspace; the library allocates nothing and keeps no global state
- *     apart from the thread-local last-error string;
+ *     workspace; the library allocates nothing.  Process-wide state is limited
+ *     to the thread-local last-error string and a cache of the YOLO_AMD_*
+ *     environment knobs (integers; see yolo_amd_reload_knobs);
+ *   - calls on different streams may run concurrently as long as they do not
+ *     share a workspace, a split-K scratch or an output buffer;
  *   - return value: 0 on success, negative on error (see yolo_amd_last_error).
  */
 #ifndef YOLO_AMD_H
@@ -25,7 +28,7 @@
 extern "C" {
 #endif
 
-#define YOLO_AMD_ABI_VERSION 4
+#define YOLO_AMD_ABI_VERSION 5
 #define YOLO_AMD_MAX_HEADS 4
 #define YOLO_AMD_MAX_ANCHORS 8
 
@@ -205,6 +208,27 @@ int yolo_amd_conv_cout_pad(int cout);
  * YOLO_AMD_SPLITK=0 to keep every reduction in one pass) are read once and
  * cached; call this after changing the environment of a running process. */
 void yolo_amd_reload_knobs(void);
+
+/* Which kernel yolo_amd_conv_forward runs for a layer, and with what tiling.
+ * No counterpart in the reference (torch picks its own kernels); it exists so
+ * that a test can assert which kernel a shape exercises, and for tuning tools.
+ * Only the shape fields of the descriptor are read, plus splitk_ws /
+ * splitk_ws_bytes (a layer is split only when it is lent enough scratch). */
+#define YOLO_AMD_KERNEL_FIRST 1 /* first layer alone (NCHW fp32 in)                   */
+#define YOLO_AMD_KERNEL_STEM  2 /* first layer + the stride-2 layer behind it          */
+#define YOLO_AMD_KERNEL_THIN  3 /* 3x3 stride 1, 32 -> 64 channels, weights in registers */
+#define YOLO_AMD_KERNEL_PATCH 4 /* 3x3 stride 1 with the input patch reused over the taps */
+#define YOLO_AMD_KERNEL_IGEMM 5 /* im2col implicit GEMM (every other layer)            */
+typedef struct {
+    int kernel;          /* YOLO_AMD_KERNEL_*                                   */
+    int bm, bn, bk;      /* output pixels x output channels per workgroup; K step */
+    int act_ksteps;      /* IGEMM: depth of the activation tile in K steps (1, 2) */
+    int lds_stages;      /* IGEMM: depth of the LDS ring                         */
+    int waves;           /* waves per workgroup                                  */
+    int taps_per_stage;  /* PATCH: taps per weight stage (1 or 3)                */
+    int k_slices;        /* > 1: split reduction + finishing launch              */
+} yolo_amd_conv_choice;
+int yolo_amd_conv_query(const yolo_amd_conv_desc* desc, yolo_amd_conv_choice* out);
 
 /* Run `n` fused layers back to back on `stream`.  descs: host array.
  * zero_page: >= 256 bytes of device memory holding zeros (padding source). */

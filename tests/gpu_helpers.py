@@ -66,7 +66,8 @@ def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None
              splitk=False, info=None):
     """One fused layer through yolo_amd_conv_forward.  splitk: lend the scratch the
     library asks for, so a layer with few output tiles splits its reduction; info (a
-    dict) receives "splitk_bytes".
+    dict) receives "splitk_bytes" and "choice" (the kernel the library picks, as
+    yolo_amd_conv_query reports it).
 
     x0: (B, H0, W0, c0) bf16 NHWC cuda; x1: optional (B, H, W, c1) bf16;
     w: (cout, cin, k, k) fp32 (already BN-folded); bias: (cout,) fp32.
@@ -107,6 +108,8 @@ def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None
     if splitk and need:
         ws = torch.full((need,), 0xFF, dtype=torch.uint8, device=dev)      # NaN-filled scratch
         d[0].splitk_ws, d[0].splitk_ws_bytes = ws.data_ptr(), need
+    if info is not None:
+        info["choice"] = _lib.conv_choice(d[0])      # which kernel the library runs for this layer
     check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), _lib.current_stream_ptr(dev)), "conv")
     torch.cuda.synchronize()
     return out
@@ -127,3 +130,49 @@ def conv_reference(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residua
     if residual is not None:
         y = y + residual.float().cpu().permute(0, 3, 1, 2)
     return y.permute(0, 2, 3, 1).contiguous()
+
+
+def case_seed(name):
+    """A fixed seed per test-case name (str hashes are salted per process)."""
+    import zlib
+    return zlib.crc32(name.encode()) % 10000
+
+
+def keep_set(pred, rows):
+    """The (image, row) pairs of `pred` (B, N, D) that the (K, 9) filter_results rows
+    stand for: a row's corner box is a pure function of one prediction row, so the
+    pairs are recovered by matching the four corner floats bit for bit."""
+    out = set()
+    if rows.shape[0] == 0:
+        return out
+    p = pred.astype(np.float32)
+    half_w, half_h = p[..., 2] / np.float32(2), p[..., 3] / np.float32(2)
+    corners = np.stack([p[..., 0] - half_w, p[..., 1] - half_h, p[..., 0] + half_w, p[..., 1] + half_h], -1)
+    for b in np.unique(rows[:, 0]).astype(int):
+        index = {}
+        for n, c in enumerate(corners[b].view(np.uint32)):
+            index.setdefault(c.tobytes(), n)
+        for r in rows[rows[:, 0] == b][:, 1:5].astype(np.float32).view(np.uint32):
+            n = index.get(r.tobytes())
+            assert n is not None, "an output row matches no prediction row"
+            out.add((b, n))
+    return out
+
+
+def record_metric(name, values):
+    """Append one entry to gpurun_out/parity_metrics.json (copied into profiles/ by
+    hand after a GPU run): what the bf16 path measured against the fp32 oracle."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "parity_metrics.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = {}
+    if os.path.exists(path):
+        try:
+            with open(path) as fh:
+                data = json.load(fh)
+        except Exception:
+            data = {}
+    data[name] = values
+    with open(path, "w") as fh:
+        json.dump(data, fh, indent=1, sort_keys=True)

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} is declared in yolo_amd.h but not exported"
         assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype in yolo_amd/_lib.py"
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.yolo_amd_abi_version() == 4
+    assert _lib.lib.yolo_amd_abi_version() == 5
 
 
 def test_struct_layouts_match_the_header():
@@ -53,6 +53,36 @@ int main(void) {
     want = [ctypes.sizeof(H), H.stride.offset, H.anchor_h.offset, ctypes.sizeof(C), C.c0.offset,
             C.first_layer.offset, C.decode.offset, C.fuse_next.offset]
     assert got == want
+
+
+def test_conv_query_reports_the_kernel_without_a_gpu():
+    """yolo_amd_conv_query reads shape fields only: the dispatch of the benchmark's
+    layer shapes can be checked on the host."""
+    from yolo_amd import _lib
+    def desc(B, H, c0, cout, k, stride, first=0, fuse=0):
+        d = _lib.ConvDesc()
+        d.B, d.H, d.W, d.c0, d.cout, d.ksize, d.stride = B, H, H, c0, cout, k, stride
+        d.cout_pad = cout if first else _lib.lib.yolo_amd_conv_cout_pad(cout)
+        d.k_pad = k * k * c0
+        d.first_layer, d.fuse_next = first, fuse
+        return d
+    q = _lib.conv_choice
+    assert q(desc(32, 416, 3, 32, 3, 1, first=1, fuse=1))["kernel"] == "stem"
+    assert q(desc(32, 416, 3, 32, 3, 1, first=1))["kernel"] == "first"
+    assert q(desc(32, 208, 32, 64, 3, 1))["kernel"] == "thin"
+    c = q(desc(32, 26, 256, 512, 3, 1))
+    assert (c["kernel"], c["waves"], c["taps_per_stage"]) == ("patch", 8, 3)
+    assert q(desc(32, 38, 256, 512, 3, 1))["kernel"] == "igemm"          # 608: 19 * 2^n maps
+    c = q(desc(32, 52, 256, 128, 1, 1))
+    assert (c["kernel"], c["bn"], c["bk"], c["act_ksteps"], c["lds_stages"]) == ("igemm", 128, 32, 2, 2)
+    c = q(desc(1, 52, 256, 128, 1, 1))
+    assert (c["kernel"], c["bn"]) == ("igemm", 64)                      # few tiles: narrower channel tile
+    c = q(desc(32, 13, 1024, 512, 1, 1))
+    assert (c["kernel"], c["bn"], c["bk"], c["act_ksteps"]) == ("igemm", 64, 64, 1)
+    bad = desc(1, 13, 48, 64, 5, 1)
+    ch = _lib.ConvChoice()
+    import ctypes
+    assert _lib.lib.yolo_amd_conv_query(ctypes.byref(bad), ctypes.byref(ch)) < 0
 
 
 def test_host_side_argument_checks_need_no_gpu():

@@ -21,7 +21,7 @@ import yolo_oracle as orc
 from helpers import assert_bit_equal, c_decode_head, c_filter_results, load_golden
 from yolo_amd.cfg import default_params
 
-from gpu_helpers import set_knob
+from gpu_helpers import case_seed, set_knob
 
 pytestmark = pytest.mark.gpu
 
@@ -77,10 +77,10 @@ CONV_CASES = [
     ("k1_c64_n32", 2, 26, 64, 32, 1, 1, True, False, 0, 0, False),        # BK=64 BN=32
     ("k3_c32_n64_res", 3, 13, 32, 64, 3, 1, True, True, 0, 0, False),     # BK=32 BN=64 + residual
     ("k3_c32_n32", 1, 20, 32, 32, 3, 1, True, False, 0, 0, False),        # BK=32 BN=32
-    ("k3s2_c64_n128", 2, 26, 64, 128, 3, 2, True, False, 0, 0, False),    # BK=64 BN=128
-    ("k1_c128_n64", 3, 13, 128, 64, 1, 1, True, False, 0, 0, False),      # BK=64 BN=64
-    ("k3_c96_n128", 1, 15, 96, 128, 3, 1, True, True, 0, 0, False),       # BK=32 BN=128 + residual
-    ("k3_c128_n256_res", 2, 13, 128, 256, 3, 1, True, True, 0, 0, False), # two channel tiles
+    ("k3s2_c64_n128", 2, 26, 64, 128, 3, 2, True, False, 0, 0, False),    # few tiles: 64-channel tiles
+    ("k1_c128_n64", 3, 13, 128, 64, 1, 1, True, False, 0, 0, False),      # BN=64
+    ("k3_c96_n128", 1, 15, 96, 128, 3, 1, True, True, 0, 0, False),       # BK=32 + residual (BN=128 cases: BN128_CASES)
+    ("k3_c128_n256_res", 2, 13, 128, 256, 3, 1, True, True, 0, 0, False), # several channel tiles
     ("head_c256_n255", 2, 13, 256, 255, 1, 1, False, False, 0, 0, True),  # detection conv, fp32 out
     ("head_c128_n9", 1, 10, 128, 9, 1, 1, False, False, 0, 0, True),      # one-anchor head
     ("route_up_c64_c128", 2, 12, 64, 64, 1, 1, True, False, 128, 1, False),   # upsample + concat
@@ -94,7 +94,7 @@ CONV_CASES = [
 def test_conv_layer(case):
     from gpu_helpers import conv_reference, run_conv
     name, B, H, c0, cout, k, stride, leaky, use_res, c1, up0, fp32_out = case
-    r = gi.rs(abs(hash(name)) % 10000)
+    r = gi.rs(case_seed(name))
     H0 = H >> up0
     x0 = torch.from_numpy(r.standard_normal((B, H0, H0, c0)).astype(np.float32)).cuda().to(torch.bfloat16)
     x1 = None
@@ -117,6 +117,96 @@ def test_conv_layer(case):
         torch.testing.assert_close(got, want, rtol=2e-4, atol=2e-4)
     else:
         torch.testing.assert_close(got, want, rtol=1.0 / 128, atol=1.0 / 128)
+
+
+# The im2col kernel takes 128-channel tiles only when ceil(M/128) * cout_pad/128 >= 384
+# (large batches): these are the shapes of the 416 / batch-32 benchmark that do, plus
+# one per instantiated (K step, ring depth) pair.  Every case asserts the kernel and
+# tiling the library reports for it, so a change of the dispatch heuristic can never
+# silently leave an instantiation without a parity check.
+BN128_CASES = [
+    # name, B, H, c0, cout, k, stride, residual, knobs, expected (bn, bk, act_ksteps, lds_stages)
+    ("bn128_k1_c256_n128_h52", 32, 52, 256, 128, 1, 1, False, {}, (128, 32, 2, 2)),          # 10 layers of the benchmark
+    ("bn128_k3s2_c256_n512_h52", 32, 52, 256, 512, 3, 2, False, {}, (128, 32, 2, 2)),        # down-sampling layer
+    ("bn128_k3s2_c64_n128_h208", 8, 208, 64, 128, 3, 2, False, {}, (128, 32, 2, 2)),
+    ("bn128_k1_c256_n256_ragged_res", 20, 50, 256, 256, 1, 1, True, {}, (128, 32, 2, 2)),    # M = 50000: ragged last tile
+    ("bn128_k1_c512_n256_h52", 16, 52, 512, 256, 1, 1, False, {}, (128, 64, 1, 2)),          # K step 64
+    ("bn128_bk64_ring3", 16, 52, 512, 256, 1, 1, True, {"YOLO_AMD_CONV_NSTAGE": "3"}, (128, 64, 1, 3)),
+    ("bn128_bk64_ring4", 16, 52, 512, 256, 1, 1, False, {"YOLO_AMD_CONV_NSTAGE": "4"}, (128, 64, 1, 4)),
+    ("bn128_bk32_amul1", 32, 52, 256, 128, 1, 1, False, {"YOLO_AMD_CONV_AMUL": "1"}, (128, 32, 1, 2)),
+    ("bn128_bk32_ring3", 32, 52, 256, 128, 1, 1, True, {"YOLO_AMD_CONV_NSTAGE": "3"}, (128, 32, 1, 3)),
+    ("bn128_bk32_ring4", 32, 52, 256, 128, 1, 1, False, {"YOLO_AMD_CONV_NSTAGE": "4"}, (128, 32, 1, 4)),
+]
+
+
+@pytest.mark.parametrize("case", BN128_CASES, ids=lambda c: c[0])
+def test_conv_layer_128_channel_tiles(case, monkeypatch):
+    from gpu_helpers import conv_reference, run_conv
+    name, B, H, c0, cout, k, stride, use_res, knobs, expect = case
+    for kn, v in knobs.items():
+        set_knob(monkeypatch, kn, v)
+    g = torch.Generator(device="cuda").manual_seed(case_seed(name))
+    x0 = torch.randn((B, H, H, c0), generator=g, device="cuda").to(torch.bfloat16)
+    r = gi.rs(case_seed(name))
+    w = torch.from_numpy((r.standard_normal((cout, c0, k, k)) * np.sqrt(2.0 / (c0 * k * k))).astype(np.float32))
+    bias = torch.from_numpy(r.normal(0, 0.3, cout).astype(np.float32))
+    Ho = (H + 2 * (k // 2) - k) // stride + 1
+    res = None
+    if use_res:
+        res = torch.randn((B, Ho, Ho, cout), generator=g, device="cuda").to(torch.bfloat16)
+    info = {}
+    got = run_conv(x0, w, bias, stride=stride, leaky=True, residual=res, info=info).float().cpu()
+    ch = info["choice"]
+    assert ch["kernel"] == "igemm" and (ch["bn"], ch["bk"], ch["act_ksteps"], ch["lds_stages"]) == expect and \
+        ch["k_slices"] == 1, f"this shape was meant for the {expect} im2col kernel, the library picked {ch}"
+    want = conv_reference(x0, w, bias, stride=stride, leaky=True, residual=res)
+    assert torch.isfinite(got).all(), "output holds NaN/inf (unwritten elements?)"
+    torch.testing.assert_close(got, want, rtol=1.0 / 128, atol=1.0 / 128)
+
+
+def test_a_detection_layer_with_decode_never_takes_the_patch_or_thin_kernel():
+    """A 3x3 stride-1 detection convolution on a 13*2^n map with cout_pad % 128 == 0
+    fits the patch kernel's shape test; that kernel has no decode epilogue, so the
+    library must route it to the im2col kernel -- and the rows must be decoded."""
+    from yolo_amd import _lib
+    from yolo_amd._lib import ConvDesc, HeadDesc, check, lib
+    from yolo_amd.engine import pack_conv_weights
+    from gpu_helpers import conv_reference
+    from helpers import c_decode_head
+    B, G, cin, A, C = 32, 26, 64, 3, 80
+    D, cout = 5 + C, 3 * 85
+    r = gi.rs(case_seed("decode_3x3"))
+    x0 = torch.from_numpy(r.standard_normal((B, G, G, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
+    w = torch.from_numpy((r.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
+    bias = torch.from_numpy(r.normal(0, 0.3, cout).astype(np.float32))
+    wp = pack_conv_weights(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin).cuda(), 256)
+    bp = torch.zeros(256, dtype=torch.float32, device="cuda")
+    bp[:cout] = bias.cuda()
+    N = G * G * A
+    out = torch.full((B, N, D), float("nan"), dtype=torch.float32, device="cuda")
+    zero = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    anchors = np.array([[30.0, 61.0], [62.0, 45.0], [59.0, 119.0]])
+    hd = HeadDesc()
+    hd.G, hd.layout, hd.row_offset, hd.stride = G, _lib.LAYOUT_NHWC, 0, 16.0
+    for a in range(A):
+        hd.anchor_w[a] = np.float32(anchors[a][0] / 16)
+        hd.anchor_h[a] = np.float32(anchors[a][1] / 16)
+    d = (ConvDesc * 1)()
+    d[0].src0, d[0].weight, d[0].bias, d[0].dst = x0.data_ptr(), wp.data_ptr(), bp.data_ptr(), out.data_ptr()
+    d[0].c0, d[0].B, d[0].H, d[0].W = cin, B, G, G
+    d[0].cout, d[0].cout_pad, d[0].ksize, d[0].stride, d[0].k_pad = cout, 256, 3, 1, 9 * cin
+    d[0].leaky, d[0].dst_fp32 = 0, 1
+    import ctypes
+    assert _lib.conv_choice(d[0])["kernel"] == "patch"            # the shape alone would take it ...
+    d[0].decode, d[0].decode_rows, d[0].decode_anchors = ctypes.pointer(hd), N, A
+    assert _lib.conv_choice(d[0])["kernel"] == "igemm"            # ... a layer that decodes does not
+    check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), _lib.current_stream_ptr(x0.device)), "conv")
+    torch.cuda.synchronize()
+    raw = conv_reference(x0, w, bias, leaky=False)                 # (B, G, G, A*D) fp32
+    want = c_decode_head(raw.permute(0, 3, 1, 2).contiguous().numpy(), anchors, 416, C)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("B,H,use_res", [(2, 40, True), (1, 21, False), (33, 16, True)])
@@ -156,7 +246,7 @@ def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     name, B, H, cin, cout, leaky, use_res, fp32_out = case
     set_knob(monkeypatch, "YOLO_AMD_CONV3", "1")
     set_knob(monkeypatch, "YOLO_AMD_CONV3_STG", stg)
-    r = gi.rs(abs(hash(name)) % 10000)
+    r = gi.rs(case_seed(name))
     x0 = torch.from_numpy(r.standard_normal((B, H, H, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
     w = torch.from_numpy((r.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
     bias = torch.from_numpy(r.normal(0, 0.3, cout).astype(np.float32))
@@ -267,6 +357,92 @@ def test_forward_416_vs_oracle_and_end_to_end(conv3, monkeypatch):
     print(f"416 e2e: HIP bf16 path keeps {out.shape[0]} rows, fp32 oracle path {ref_rows.shape[0]}")
 
 
+# ------------------------------------------------------------------ the benchmark configurations
+# bf16 bar: boxes and scores within 1e-2 relative of the fp32 reference path.  What is
+# gated: the per-layer relative L2 error (3e-2), the share of output elements inside
+# 1e-2 relative (rel = |got - want| / (|want| + 1e-3)), the objectness error, and
+# bit-exact NMS rows given the HIP prediction.  The shares and the bf16-vs-fp32
+# keep-set agreement (Jaccard index of the kept (image, box) pairs) are written to
+# gpurun_out/parity_metrics.json; the committed copy is profiles/round2_parity_metrics.json.
+CONFIG_CASES = [
+    # name, H, B, C, A, minimum share of elements within 1e-2 relative
+    ("cfg2_416_b32", 416, 32, 80, 3, 0.90),         # the benchmark configuration: batch-32 dispatch
+    ("cfg3_608_b2", 608, 2, 80, 3, 0.90),           # 19 * 2^n maps: ragged tiles, no patch kernel
+    ("cfg5a_320_b1", 320, 1, 80, 3, 0.90),          # video latency: split reductions
+    ("cfg5b_320_b1_a1c4", 320, 1, 4, 1, 0.90),      # one-anchor variant
+]
+
+
+@pytest.mark.parametrize("case", CONFIG_CASES, ids=lambda c: c[0])
+def test_forward_benchmark_configurations(case):
+    from gpu_helpers import build_model, keep_set, oracle_forward, record_metric
+    from yolo_amd import _lib
+    from yolo_amd.engine import Plan
+    from yolo_amd.utilis import filter_results
+    name, H, B, C, A, min_share = case
+    model, params, sd = build_model(H, C, A)
+    x_np = gi.images(21, B, H)
+    x = torch.from_numpy(x_np).cuda()
+    det = model(x)
+    torch.cuda.synchronize()
+    N = A * ((H // 32) ** 2 + (H // 16) ** 2 + (H // 8) ** 2)
+    assert tuple(det.shape) == (B, N, 5 + C)
+
+    # which kernels the default plan of this configuration runs
+    plan = model._plan(B, H)
+    kinds = {}
+    for j in range(len(plan.ops)):
+        ch = _lib.conv_choice(plan.descs[j])
+        key = (ch["kernel"], ch["bn"], ch["bk"], ch["act_ksteps"]) if ch["kernel"] == "igemm" else (ch["kernel"],)
+        kinds[key] = kinds.get(key, 0) + 1
+    print(f"\n{name}: kernels {kinds}")
+    if name == "cfg2_416_b32":
+        assert kinds.get(("igemm", 128, 32, 2), 0) >= 10, "batch 32 was meant to run the 128-channel-tile kernel"
+        assert kinds.get(("patch",), 0) >= 25 and kinds.get(("stem",), 0) == 1 and kinds.get(("thin",), 0) == 1
+    if name == "cfg3_608_b2":
+        assert ("patch",) not in kinds
+
+    want_t, outs = oracle_forward(sd, H, C, A, x_np, return_layers=True)
+    keep = Plan(model, B, H, keep_all=True)
+    det_keep = keep.run(x)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for op in keep.ops:
+        i = op["index"]
+        ref = outs[i + 1] if op["res"] else outs[i]
+        err = _rel_err(keep.layer_output(i).float().cpu().numpy(), ref.permute(0, 2, 3, 1).numpy())
+        worst = max(worst, err)
+        assert err < 0.03, f"conv block {i}: relative L2 error {err:.4f} vs the fp32 oracle"
+    del outs, keep
+    got, want = det.cpu().numpy(), want_t.numpy()
+    # the layer-by-layer plan runs the first two layers separately and its own decode
+    # launch: same values as the fused plan
+    assert torch.equal(det_keep, det), "fused stem / fused decode change the result"
+    rel = np.abs(got - want) / (np.abs(want) + 1e-3)
+    share = float((rel <= 1e-2).mean())
+    share_box = float((rel[..., :4] <= 1e-2).mean())
+    share_obj = float((rel[..., 4] <= 1e-2).mean())
+    obj_err = float(np.abs(got[..., 4] - want[..., 4]).max())
+    out = filter_results(det, params)
+    rows = c_filter_results(got, params["confidence"], params["nms_thesh"], C)
+    if rows.shape[0] == 0:
+        assert isinstance(out, int) and out == 0
+    else:
+        assert_bit_equal(out.cpu().numpy(), rows, f"{name}: NMS rows given the HIP prediction")
+    ref_rows = c_filter_results(want, params["confidence"], params["nms_thesh"], C)
+    ks_hip, ks_ref = keep_set(got, rows), keep_set(want, ref_rows)
+    jac = len(ks_hip & ks_ref) / max(1, len(ks_hip | ks_ref))
+    metrics = dict(H=H, B=B, C=C, A=A, worst_layer_rel_l2=round(worst, 5), share_within_1e2=round(share, 5),
+                   share_within_1e2_boxes=round(share_box, 5), share_within_1e2_objectness=round(share_obj, 5),
+                   median_rel=float(np.median(rel)), p99_rel=float(np.percentile(rel, 99)),
+                   objectness_abs_err_max=obj_err, rows_hip=int(rows.shape[0]), rows_fp32=int(ref_rows.shape[0]),
+                   keep_set_jaccard=round(jac, 5), kernels={"/".join(map(str, k)): v for k, v in kinds.items()})
+    print(f"{name}: {metrics}")
+    record_metric(name, metrics)
+    assert share >= min_share, f"only {share:.3f} of the output elements are within 1e-2 relative"
+    assert np.median(rel) < 1e-2 and obj_err < 0.05
+
+
 def test_batch_consistency_and_plan_reuse(monkeypatch):
     from gpu_helpers import build_model
     model, params, _ = build_model(96)
@@ -308,7 +484,7 @@ def test_split_reduction_matches_the_reference_and_the_single_pass(case):
     to the single-pass tolerance, and stay within rounding of the single pass."""
     from gpu_helpers import conv_reference, run_conv
     name, B, H, c0, cout, k, stride, leaky, use_res, fp32_out = case
-    r = gi.rs(abs(hash(name)) % 10000)
+    r = gi.rs(case_seed(name))
     x0 = torch.from_numpy(r.standard_normal((B, H, H, c0)).astype(np.float32)).cuda().to(torch.bfloat16)
     w = torch.from_numpy((r.standard_normal((cout, c0, k, k)) * np.sqrt(2.0 / (c0 * k * k))).astype(np.float32))
     bias = torch.from_numpy(r.normal(0, 0.3, cout).astype(np.float32))

@@ -114,6 +114,50 @@ def test_detection_pipeline_returns_what_the_two_calls_return():
             assert torch.equal(g.view(torch.int32), w.view(torch.int32))
 
 
+def test_detection_pipeline_with_a_partial_last_batch_and_unclone_results():
+    """Batches of 3, 3, 2, 3 images (a loader's partial batch in the middle and at the
+    end): the buffers are replaced on every shape change, and the result pending at
+    that moment must still come back.  Results are NOT cloned here: a handed-out view
+    stays valid until the second submit() after the one that returned it."""
+    from gpu_helpers import build_model
+    from yolo_amd.harness import DetectionPipeline
+    from yolo_amd.utilis import filter_results
+    model, params, _ = build_model(96)
+    params = dict(params)
+    params["confidence"], params["nms_thesh"] = 0.3, 0.4
+    sizes = [3, 3, 2, 3, 3, 3, 2]
+    batches = [torch.from_numpy(gi.images(70 + i, b, 96)).cuda() for i, b in enumerate(sizes)]
+    want = []
+    for x in batches:
+        out = filter_results(model(x), params)
+        want.append(out if isinstance(out, int) else out.clone())
+    assert any(not isinstance(w, int) for w in want)
+    pipe = DetectionPipeline(model, params)
+    held = []                                   # (index, view) still inside its promised lifetime
+    n_checked = 0
+
+    def check(i, g):
+        w = want[i]
+        if isinstance(w, int):
+            assert isinstance(g, int) and g == 0, f"batch {i}"
+        else:
+            assert not isinstance(g, int), f"batch {i}: detections lost"
+            assert torch.equal(g.view(torch.int32), w.view(torch.int32)), f"batch {i}"
+
+    for j, x in enumerate(batches):
+        done = pipe.submit(x)
+        # views returned by the previous submit() are still valid after this one
+        for i, g in held:
+            check(i, g)
+            n_checked += 1
+        held = []
+        if done is not None:
+            check(j - 1, done)
+            held.append((j - 1, done))
+    check(len(batches) - 1, pipe.flush())
+    assert n_checked == len(batches) - 2
+
+
 @pytest.mark.parametrize("train", [False, True])
 @pytest.mark.parametrize("name", ["coco_sweep", "four_class", "single_conf"])
 def test_get_map_with_hip_detections_matches_the_reference(name, train):

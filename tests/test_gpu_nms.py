@@ -75,6 +75,72 @@ def test_nms_stress_batch():
     assert (np.diff(obj)[same] <= 0).all()
 
 
+def test_nms_stress_batch_64():
+    """The NMS-stress configuration at its full size: batch 64, 10647 boxes x 80
+    classes per image, conf 0.01 (474 MB of workspace).  Bit-exact against the C
+    oracle on the whole batch, plus the size-independent properties: ordering, every
+    row above the threshold, no two kept boxes of one (image, class) with IoU >= the
+    threshold, and idempotence (NMS of the kept rows keeps them all)."""
+    from helpers import c_box_iou
+    from yolo_amd._lib import lib
+    B, N, C = 64, 10647, 80
+    assert lib.yolo_amd_filter_results_workspace_bytes(B, N, C) > 400 << 20
+    pred = gi.nms_pred(seed=68, B=B, N=N, C=C)
+    pred[:, ::2] = gi.nms_pred(seed=69, B=B, N=(N + 1) // 2, C=C, mode="clustered")   # half the boxes crowd
+    out = hip_filter(pred, 0.01, 0.4, C).cpu().numpy()
+    want = c_filter_results(pred, 0.01, 0.4, C)
+    assert_bit_equal(out, want, "stress batch 64")
+    img, cls, obj = out[:, 0], out[:, 7], out[:, 5]
+    key = img * 1000 + cls
+    assert (np.diff(key) >= 0).all()
+    assert (np.diff(obj)[np.diff(key) == 0] <= 0).all()
+    assert (obj > np.float32(0.01)).all() and set(np.unique(img).astype(int)) == set(range(B))
+    # pairwise IoU inside a few crowded (image, class) groups
+    checked = 0
+    for b, c in [(0, 0), (17, 7), (63, 79), (40, 35)]:
+        grp = out[(img == b) & (cls == c)][:, 1:5]
+        for i in range(min(len(grp) - 1, 40)):
+            assert (c_box_iou(grp[i:i + 1], grp[i + 1:]) < np.float32(0.4)).all()
+            checked += 1
+    assert checked > 20
+    # idempotence on the first four images: feed the kept boxes back in
+    sub = out[img < 4]
+    again = np.zeros((4, int(np.bincount(sub[:, 0].astype(int)).max()), 5 + C), dtype=np.float32)
+    for b in range(4):
+        rb = sub[sub[:, 0] == b]
+        n = len(rb)
+        again[b, :n, 0] = (rb[:, 1] + rb[:, 3]) / 2
+        again[b, :n, 1] = (rb[:, 2] + rb[:, 4]) / 2
+        again[b, :n, 2] = rb[:, 3] - rb[:, 1]
+        again[b, :n, 3] = rb[:, 4] - rb[:, 2]
+        again[b, :n, 4] = rb[:, 5]
+        again[b, np.arange(n), 5 + rb[:, 7].astype(int)] = rb[:, 6]
+    out2 = hip_filter(again, 0.01, 0.4, C).cpu().numpy()
+    assert_bit_equal(out2, c_filter_results(again, 0.01, 0.4, C), "second pass")
+    # (re-centred boxes differ in the last bit, so the second pass may drop a handful)
+    assert out2.shape[0] >= 0.99 * sub.shape[0]
+
+
+def test_two_streams_do_not_share_a_workspace():
+    """filter_results keeps one workspace per (device, stream): two calls queued on
+    different streams may overlap on the GPU and must still both be right."""
+    from yolo_amd.utilis import filter_results_async
+    preds = [gi.nms_pred(seed=90 + i, B=4, N=3000, C=80, mode="clustered") for i in range(2)]
+    want = [c_filter_results(p, 0.05, 0.4, 80) for p in preds]
+    ts = [torch.from_numpy(p).cuda() for p in preds]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    params = {"confidence": 0.05, "nms_thesh": 0.4, "num_classes": 80}
+    torch.cuda.synchronize()
+    for rep in range(3):
+        pending = []
+        for t, st in zip(ts, streams):
+            with torch.cuda.stream(st):
+                pending.append(filter_results_async(t, params))      # nothing waits: the two overlap
+        for o, w in zip(pending, want):
+            assert_bit_equal(o.result().cpu().numpy(), w, f"stream result, repetition {rep}")
+    assert filter_results_async(ts[0][:, :0], params).result() == 0
+
+
 def test_single_class_large_segment():
     # one class, thousands of boxes in one segment, ties included
     pred = gi.nms_pred(seed=63, B=2, N=5000, C=1, mode="clustered", tie_levels=256)

@@ -91,45 +91,6 @@ def test_snapshot_constructor_and_cpu_forward_is_refused(cfg_path):
         model(torch.zeros(1, 3, 64, 64), is_training=True)
 
 
-def test_darknet_weights_reader(cfg_path):
-    """Write a synthetic .weights file in Darknet order and read it back."""
-    blocks = parse_cfg(cfg_path)
-    table = orc.layer_table(orc.parse_cfg(cfg_path), 3, 80, 3)
-    sd = gi.synthetic_state_dict(table, 7)
-    chunks = [np.array([0, 2, 0, 123, 0], dtype=np.int32).tobytes()]
-    for i, ent in enumerate(table):
-        if ent["type"] != "conv":
-            continue
-        if ent["bn"]:
-            p = f"module_list.{i}.bach_norm_{i}."
-            for k in ("bias", "weight", "running_mean", "running_var"):
-                chunks.append(sd[p + k].tobytes())
-        else:
-            chunks.append(sd[f"module_list.{i}.conv_{i}.bias"].tobytes())
-        chunks.append(sd[f"module_list.{i}.conv_{i}.weight"].tobytes())
-    with tempfile.NamedTemporaryFile(suffix=".weights", delete=False) as fh:
-        fh.write(b"".join(chunks))
-    params = default_params(64)
-    model = yolo_v3(params, blocks, weight_file=None)
-    model.load_weights(fh.name)
-    os.remove(fh.name)
-    got = model.state_dict()
-    for k, v in sd.items():
-        if "num_batches" in k:
-            continue
-        assert np.array_equal(got[k].numpy(), v), k
-    assert int(model.seen) == 123
-    # cust_train_zero zero-fills the detection convs (so objectness is exactly 0.5)
-    model2 = yolo_v3(default_params(64), parse_cfg(cfg_path), weight_file=None)
-    with tempfile.NamedTemporaryFile(suffix=".weights", delete=False) as fh:
-        fh.write(b"".join(chunks))
-    model2.load_weights(fh.name, cust_train_zero=True)
-    os.remove(fh.name)
-    assert float(model2.state_dict()["module_list.81.conv_81.weight"].abs().sum()) == 0.0
-    assert np.array_equal(model2.state_dict()["module_list.80.conv_80.weight"].numpy(),
-                          sd["module_list.80.conv_80.weight"])
-
-
 @pytest.mark.parametrize("B,H", [(32, 416), (1, 320), (32, 608), (2, 64)])
 def test_fused_plan_structure_and_buffer_placement(B, H):
     blocks = orc.parse_cfg_text(yolov3_cfg_text())

@@ -63,6 +63,17 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class ConvChoice(ctypes.Structure):
+    """yolo_amd_conv_choice of include/yolo_amd.h."""
+    _fields_ = [("kernel", ctypes.c_int), ("bm", ctypes.c_int), ("bn", ctypes.c_int), ("bk", ctypes.c_int),
+                ("act_ksteps", ctypes.c_int), ("lds_stages", ctypes.c_int), ("waves", ctypes.c_int),
+                ("taps_per_stage", ctypes.c_int), ("k_slices", ctypes.c_int)]
+
+
+KERNEL_FIRST, KERNEL_STEM, KERNEL_THIN, KERNEL_PATCH, KERNEL_IGEMM = 1, 2, 3, 4, 5
+KERNEL_NAMES = {1: "first", 2: "stem", 3: "thin", 4: "patch", 5: "igemm"}
+
+
 # name -> (restype, argtypes); every symbol include/yolo_amd.h declares
 SYMBOLS = {
     "yolo_amd_last_error": (ctypes.c_char_p, []),
@@ -92,6 +103,7 @@ SYMBOLS = {
     "yolo_amd_reload_knobs": (None, []),
     "yolo_amd_conv_splitk_bytes": (ctypes.c_size_t, [ctypes.POINTER(ConvDesc)]),
     "yolo_amd_conv_cout_pad": (ctypes.c_int, [ctypes.c_int]),
+    "yolo_amd_conv_query": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvChoice)]),
     "yolo_amd_conv_forward": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p]),
 }
@@ -114,7 +126,7 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    want = 4
+    want = 5
     got = lib.yolo_amd_abi_version()
     if got != want:
         raise ImportError(f"{LIB_PATH} has ABI version {got}, the Python side expects {want}")
@@ -122,6 +134,15 @@ def _load():
 
 
 lib = _load()
+
+
+def conv_choice(desc):
+    """The kernel the library would run for one ConvDesc, as a dict."""
+    c = ConvChoice()
+    check(lib.yolo_amd_conv_query(ctypes.byref(desc), ctypes.byref(c)), "conv_query")
+    return {"kernel": KERNEL_NAMES[c.kernel], "bm": c.bm, "bn": c.bn, "bk": c.bk, "act_ksteps": c.act_ksteps,
+            "lds_stages": c.lds_stages, "waves": c.waves, "taps_per_stage": c.taps_per_stage,
+            "k_slices": c.k_slices}
 
 
 def check(rc, what):

@@ -623,8 +623,9 @@ struct Conv3Args {
     int leaky, dst_fp32;
     int tiles_y, tiles_x, ntiles;      // spatial tiles per image (y, x) and in the batch
     int tiles_n;                       // channel tiles
-    long long* trace;                  // development aid (YOLO_AMD_CONV3_TRACE=<device address>): per workgroup
-                                       // eight words: 100 MHz timestamps (start, K loop entered, K loop done, stores issued), XCC_ID << 32 | HW_ID
+    long long* trace;                  // development aid, always null unless the file is built with -DYOLO_AMD_DEV_TRACE
+                                       // (then YOLO_AMD_CONV3_TRACE=<device address>): per workgroup eight words:
+                                       // 100 MHz timestamps (start, K loop entered, K loop done, stores issued), XCC_ID << 32 | HW_ID
     int prio;                          // raise the wave priority over the MFMA groups (about 1 %; YOLO_AMD_CONV3_PRIO=0 turns it off)
 };
 
@@ -1571,7 +1572,10 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-// a device address handed over in the environment (development aid); cached like the other knobs
+#ifdef YOLO_AMD_DEV_TRACE
+// a device address handed over in the environment (tools/conv3_trace.py builds its own
+// copy of the library with this enabled; the shipped library never reads an address
+// from the environment); cached like the other knobs
 static void* env_ptr(const char* name) {
     static std::mutex m;
     static const char* cached_name = nullptr;
@@ -1586,6 +1590,7 @@ static void* env_ptr(const char* name) {
     }
     return cached;
 }
+#endif
 
 // Channel tile of the im2col kernel for a layer with M output pixels.
 static int choose_bn(const yolo_amd_conv_desc& d, long long M) {
@@ -1618,48 +1623,53 @@ static void splitk_for(const yolo_amd_conv_desc& d, int* steps, int* slices) {
     splitk_plan(((M + 127) / 128) * (d.cout_pad / BN), d.ksize * d.ksize * (d.c0 + d.c1) / 32, steps, slices);
 }
 
-static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream) {
-    YA_REQUIRE(d.src0 && d.weight && d.bias && d.dst, "conv: null pointer");
+// What launch_conv will run for a layer: the kernel family and its tile
+// parameters.  yolo_amd_conv_query hands this to callers, so a test can assert
+// which kernel a shape exercises.
+struct ConvChoice {
+    int kernel = 0;                 // YOLO_AMD_KERNEL_*
+    int bm = 0, bn = 0, bk = 0;     // output pixels x channels per workgroup, K step
+    int amul = 1, nstage = 0;       // im2col kernel: activation tile depth in K steps, LDS ring depth
+    int waves = 4;                  // waves per workgroup
+    int stg = 0;                    // patch kernel: taps per weight stage
+    int ksteps = 0, kslices = 1;    // split reduction: K-steps (of 32) per slice, slices
+    int Ho = 0, Wo = 0;
+    long long M = 0;
+};
+
+// Validates the descriptor and decides the kernel.  with_ptrs = false checks the
+// shape fields only (the query entry point works on descriptors without buffers).
+static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* out) {
+    ConvChoice c;
+    if (with_ptrs) YA_REQUIRE(d.src0 && d.weight && d.bias && d.dst, "conv: null pointer");
     YA_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.cout > 0, "conv: bad shape");
     YA_REQUIRE((d.ksize == 1 || d.ksize == 3) && (d.stride == 1 || d.stride == 2),
                "conv: ksize=%d stride=%d unsupported", d.ksize, d.stride);
     const int pad = d.ksize / 2;
-    const int Ho = (d.H + 2 * pad - d.ksize) / d.stride + 1;
-    const int Wo = (d.W + 2 * pad - d.ksize) / d.stride + 1;
-    const long long M = (long long)d.B * Ho * Wo;
-    YA_REQUIRE(M < (1ll << 31), "conv: too many output pixels");
+    c.Ho = (d.H + 2 * pad - d.ksize) / d.stride + 1;
+    c.Wo = (d.W + 2 * pad - d.ksize) / d.stride + 1;
+    c.M = (long long)d.B * c.Ho * c.Wo;
+    YA_REQUIRE(c.M < (1ll << 31), "conv: too many output pixels");
     if (d.first_layer) {
         YA_REQUIRE(d.ksize == 3 && d.stride == 1 && d.c0 >= 1 && d.c0 <= 3 && d.c1 == 0 && !d.residual &&
-                       !d.dst_fp32 && d.up0 == 0,
+                       !d.dst_fp32 && d.up0 == 0 && !d.decode,
                    "conv: first layer must be 3x3 stride 1 with at most 3 input channels");
-        const long long src_bytes = (long long)d.B * d.c0 * d.H * d.W * 4, dst_bytes = M * d.cout * 2;
-        YA_REQUIRE(src_bytes < (1ll << 31) && dst_bytes < 0xFFFFFF00ll,
-                   "conv: first layer input must be smaller than 2 GiB and its output smaller than 4 GiB");
-        const int tiles_x = (d.W + FIRST_TW - 1) / FIRST_TW, tiles_y = (d.H + FIRST_TH - 1) / FIRST_TH;
-        const long long ntiles = (long long)tiles_x * tiles_y * d.B;
-        dim3 grid((unsigned)std::min<long long>(ntiles, 256 * 8 * 4));
-        const float slope = d.leaky ? 0.1f : 1.0f;
-#define YA_FIRST(CO)                                                                               \
-    hipLaunchKernelGGL((conv_first_kernel<CO>), grid, dim3(256), 0, stream, (const float*)d.src0, \
-                       (const float*)d.weight, d.bias, (__bf16*)d.dst, d.B, d.c0, d.H, d.W, slope, \
-                       (uint32_t)src_bytes, (uint32_t)dst_bytes, tiles_x, tiles_y)
-        if (d.cout == 32) YA_FIRST(32);
-        else if (d.cout == 16) YA_FIRST(16);
-        else {
-            set_error("conv: first layer with %d output channels is not instantiated (16 or 32)", d.cout);
-            return YA_ERR_UNSUPPORTED;
-        }
-#undef YA_FIRST
+        YA_REQUIRE(d.cout == 32 || d.cout == 16,
+                   "conv: first layer with %d output channels is not instantiated (16 or 32)", d.cout);
+        c.kernel = d.fuse_next ? YOLO_AMD_KERNEL_STEM : YOLO_AMD_KERNEL_FIRST;
+        c.bm = d.fuse_next ? STEM_TY * STEM_TX : FIRST_TH * FIRST_TW;
+        c.bn = d.fuse_next ? 64 : d.cout;
+        c.bk = 32;
+        *out = c;
         return YA_OK;
     }
-    YA_REQUIRE(zero_page, "conv: zero page missing");
     YA_REQUIRE(d.c0 % 32 == 0 && d.c1 % 32 == 0 && d.c0 > 0 && d.c1 >= 0,
                "conv: input channels (%d, %d) must be multiples of 32", d.c0, d.c1);
-    YA_REQUIRE(d.c1 == 0 || d.src1, "conv: src1 missing");
+    if (with_ptrs) YA_REQUIRE(d.c1 == 0 || d.src1, "conv: src1 missing");
     YA_REQUIRE(d.up0 == 0 || (d.up0 == 1 && d.ksize == 1 && d.H % 2 == 0 && d.W % 2 == 0),
                "conv: an upsampled source is supported for 1x1 convolutions only");
     int BK = pick_bk(d.c0, d.c1);
-    const int BN = choose_bn(d, M);
+    const int BN = choose_bn(d, c.M);
     // K tile 32 keeps LDS at 32 KiB per workgroup (more resident workgroups);
     // 64 only pays for the widest inputs
     const int want_bk = env_int("YOLO_AMD_CONV_BK", (d.c0 + d.c1 >= 512) ? 64 : 32);
@@ -1669,17 +1679,25 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     YA_REQUIRE(d.cout_pad % BN == 0 && d.cout_pad >= d.cout, "conv: cout_pad=%d not a multiple of %d", d.cout_pad, BN);
     YA_REQUIRE((long long)d.B * d.H * d.W * (d.c0 + d.c1) < (1ll << 31) && (long long)d.cout_pad * K < (1ll << 31),
                "conv: tensor too large for 32-bit element offsets");
+    if (d.decode) {
+        // the head decode (yolo_v3.predict) lives in the im2col kernel's fp32 epilogue
+        // and in the split reduction's finishing kernel only: a detection layer never
+        // takes the thin or the patch kernel
+        const yolo_amd_head_desc& hd = *d.decode;
+        const int A = d.decode_anchors;
+        YA_REQUIRE(d.dst_fp32 && !d.residual && A >= 1 && A <= YOLO_AMD_MAX_ANCHORS && d.cout % A == 0 &&
+                       d.cout / A >= 5 && c.Ho == c.Wo && hd.G == c.Ho,
+                   "conv: fused decode needs an fp32, residual-free layer with cout = A*D on a GxG map");
+        YA_REQUIRE(hd.row_offset >= 0 && hd.row_offset + c.Ho * c.Wo * A <= d.decode_rows,
+                   "conv: fused decode rows [%d, %d) fall outside %d", hd.row_offset,
+                   hd.row_offset + c.Ho * c.Wo * A, d.decode_rows);
+    }
     // 3x3 stride-1 32 -> 64 channels: the thin kernel (YOLO_AMD_THIN=0: development knob)
     if (d.ksize == 3 && d.stride == 1 && d.c0 == 32 && d.c1 == 0 && d.up0 == 0 && d.cout == 64 &&
-        d.cout_pad == 64 && !d.dst_fp32 && env_int("YOLO_AMD_THIN", 1)) {
-        ThinArgs t;
-        t.src = (const __bf16*)d.src0; t.wgt = (const __bf16*)d.weight; t.bias = d.bias;
-        t.res = (const __bf16*)d.residual; t.dst = (__bf16*)d.dst; t.zero = (const __bf16*)zero_page;
-        t.B = d.B; t.H = d.H; t.W = d.W; t.leaky = d.leaky;
-        t.tiles_x = (d.W + THIN_TX - 1) / THIN_TX; t.tiles_y = (d.H + THIN_TY - 1) / THIN_TY;
-        const long long ntiles = (long long)t.tiles_x * t.tiles_y * d.B;
-        hipLaunchKernelGGL(conv3x3_thin_kernel, dim3((unsigned)std::min<long long>(ntiles, 256 * 2)), dim3(256), 0,
-                           stream, t);
+        d.cout_pad == 64 && !d.dst_fp32 && !d.decode && env_int("YOLO_AMD_THIN", 1)) {
+        c.kernel = YOLO_AMD_KERNEL_THIN;
+        c.bm = THIN_TY * THIN_TX; c.bn = 64; c.bk = 32;
+        *out = c;
         return YA_OK;
     }
     // Stride-1 3x3 layers on 13*2^n feature maps can take the patch-reuse kernel.
@@ -1695,7 +1713,84 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     const long long p3_groups = (long long)d.B * (d.H / P3_TS) * (d.W / P3_TS) * (d.cout_pad / 128);
     const int p3 = env_int("YOLO_AMD_CONV3", -1);
     if (d.ksize == 3 && d.stride == 1 && d.c1 == 0 && d.up0 == 0 && d.H % P3_TS == 0 && d.W % P3_TS == 0 &&
-        d.cout_pad % 128 == 0 && (p3 == 1 || (p3 < 0 && p3_groups >= env_int("YOLO_AMD_CONV3_MIN", 128)))) {
+        d.cout_pad % 128 == 0 && !d.decode &&
+        (p3 == 1 || (p3 < 0 && p3_groups >= env_int("YOLO_AMD_CONV3_MIN", 128)))) {
+        c.kernel = YOLO_AMD_KERNEL_PATCH;
+        c.bm = P3_NPIX; c.bn = 128; c.bk = 32;
+        c.stg = env_int("YOLO_AMD_CONV3_STG", 3) == 3 ? 3 : 1;
+        c.waves = env_int("YOLO_AMD_CONV3_WAVES", (c.stg == 3 || p3_groups <= 1536) ? 8 : 4) == 8 ? 8 : 4;
+        if (c.waves == 4) c.stg = 1;
+        *out = c;
+        return YA_OK;
+    }
+    c.kernel = YOLO_AMD_KERNEL_IGEMM;
+    c.bm = 128; c.bn = BN; c.bk = BK;
+    // Defaults from A/B timing on MI355X (tools/conv_bench.py): a two-stage ring
+    // with three or four resident workgroups per CU beats deeper rings at one
+    // workgroup per CU on every layer shape of the network.
+    c.nstage = env_int("YOLO_AMD_CONV_NSTAGE", 2);
+    // two-step activation tile (whole 128-byte lines per pixel): needs both
+    // sources in whole 64-channel groups; not worth it for the shortest K loops
+    const int amul = env_int("YOLO_AMD_CONV_AMUL", K >= 256 ? 2 : 1);
+    c.amul = (amul == 2 && BK == 32 && c.nstage == 2 && d.c0 % 64 == 0 && d.c1 % 64 == 0) ? 2 : 1;
+    if (c.amul == 1) {
+        // instantiated ring depths per tile shape
+        const bool deep3 = (BK == 32 && BN != 32) || (BN == 128 && BK == 64);
+        const bool deep4 = !(BN == 32 && BK == 32);
+        if (!((c.nstage == 3 && deep3) || (c.nstage == 4 && deep4))) c.nstage = 2;
+    }
+    // Split reduction (see conv_splitk_finish_kernel): when the caller lent a
+    // workspace and the layer has too few output tiles to occupy the chip.
+    if (d.splitk_ws) {
+        int steps, slices;
+        splitk_for(d, &steps, &slices);
+        if (slices > 1 && (size_t)slices * (size_t)c.M * d.cout * sizeof(float) <= d.splitk_ws_bytes) {
+            YA_REQUIRE(((uintptr_t)d.splitk_ws & 15) == 0, "conv: split-K workspace must be 16-byte aligned");
+            c.ksteps = steps; c.kslices = slices;
+        }
+    }
+    *out = c;
+    return YA_OK;
+}
+
+static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream) {
+    ConvChoice c;
+    const int rc = choose_conv(d, true, &c);
+    if (rc != YA_OK) return rc;
+    const int Ho = c.Ho, Wo = c.Wo;
+    const long long M = c.M;
+    if (c.kernel == YOLO_AMD_KERNEL_FIRST) {
+        const long long src_bytes = (long long)d.B * d.c0 * d.H * d.W * 4, dst_bytes = M * d.cout * 2;
+        YA_REQUIRE(src_bytes < (1ll << 31) && dst_bytes < 0xFFFFFF00ll,
+                   "conv: first layer input must be smaller than 2 GiB and its output smaller than 4 GiB");
+        const int tiles_x = (d.W + FIRST_TW - 1) / FIRST_TW, tiles_y = (d.H + FIRST_TH - 1) / FIRST_TH;
+        const long long ntiles = (long long)tiles_x * tiles_y * d.B;
+        dim3 grid((unsigned)std::min<long long>(ntiles, 256 * 8 * 4));
+        const float slope = d.leaky ? 0.1f : 1.0f;
+#define YA_FIRST(CO)                                                                               \
+    hipLaunchKernelGGL((conv_first_kernel<CO>), grid, dim3(256), 0, stream, (const float*)d.src0, \
+                       (const float*)d.weight, d.bias, (__bf16*)d.dst, d.B, d.c0, d.H, d.W, slope, \
+                       (uint32_t)src_bytes, (uint32_t)dst_bytes, tiles_x, tiles_y)
+        if (d.cout == 32) YA_FIRST(32);
+        else YA_FIRST(16);
+#undef YA_FIRST
+        return YA_OK;
+    }
+    YA_REQUIRE(c.kernel != YOLO_AMD_KERNEL_STEM, "conv: fuse_next is handled by yolo_amd_conv_forward");
+    YA_REQUIRE(zero_page, "conv: zero page missing");
+    const int K = d.ksize * d.ksize * (d.c0 + d.c1);
+    if (c.kernel == YOLO_AMD_KERNEL_THIN) {
+        ThinArgs t;
+        t.src = (const __bf16*)d.src0; t.wgt = (const __bf16*)d.weight; t.bias = d.bias;
+        t.res = (const __bf16*)d.residual; t.dst = (__bf16*)d.dst; t.zero = (const __bf16*)zero_page;
+        t.B = d.B; t.H = d.H; t.W = d.W; t.leaky = d.leaky;
+        t.tiles_x = (d.W + THIN_TX - 1) / THIN_TX; t.tiles_y = (d.H + THIN_TY - 1) / THIN_TY;
+        const long long ntiles = (long long)t.tiles_x * t.tiles_y * d.B;
+        hipLaunchKernelGGL(conv3x3_thin_kernel, dim3((unsigned)std::min<long long>(ntiles, 256 * 2)), dim3(256), 0,
+                           stream, t);
+        return YA_OK;
+    }
+    if (c.kernel == YOLO_AMD_KERNEL_PATCH) {
         Conv3Args p;
         p.src = (const __bf16*)d.src0; p.wgt = (const __bf16*)d.weight; p.bias = d.bias;
         p.res = (const __bf16*)d.residual; p.dst = d.dst; p.zero = (const __bf16*)zero_page;
@@ -1703,17 +1798,19 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.tiles_y = d.H / P3_TS; p.tiles_x = d.W / P3_TS; p.ntiles = d.B * p.tiles_y * p.tiles_x;
         p.tiles_n = d.cout_pad / 128;
         p.prio = env_int("YOLO_AMD_CONV3_PRIO", 3);
+        p.trace = nullptr;
+#ifdef YOLO_AMD_DEV_TRACE
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
-        const int stg = env_int("YOLO_AMD_CONV3_STG", 3);
-        const int p3w = env_int("YOLO_AMD_CONV3_WAVES", (stg == 3 || p3_groups <= 1536) ? 8 : 4);
-        if (p3w == 8 && stg == 3)
+#endif
+        if (c.waves == 8 && c.stg == 3)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
-        else if (p3w == 8)
+        else if (c.waves == 8)
             hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else
             hipLaunchKernelGGL(conv3x3_patch_kernel<4>, dim3(p.ntiles * p.tiles_n), dim3(256), 0, stream, p);
         return YA_OK;
     }
+    const int BN = c.bn, BK = c.bk, ns = c.nstage;
     ConvArgs a;
     a.src0 = (const __bf16*)d.src0; a.src1 = (const __bf16*)d.src1; a.wgt = (const __bf16*)d.weight;
     a.bias = d.bias; a.res = (const __bf16*)d.residual; a.dst = d.dst; a.zero = (const __bf16*)zero_page;
@@ -1726,12 +1823,6 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     if (d.decode) {
         const yolo_amd_head_desc& hd = *d.decode;
         const int A = d.decode_anchors;
-        YA_REQUIRE(d.dst_fp32 && !d.residual && A >= 1 && A <= YOLO_AMD_MAX_ANCHORS && d.cout % A == 0 &&
-                       d.cout / A >= 5 && Ho == Wo && hd.G == Ho,
-                   "conv: fused decode needs an fp32, residual-free layer with cout = A*D on a GxG map");
-        YA_REQUIRE(hd.row_offset >= 0 && hd.row_offset + Ho * Wo * A <= d.decode_rows,
-                   "conv: fused decode rows [%d, %d) fall outside %d", hd.row_offset,
-                   hd.row_offset + Ho * Wo * A, d.decode_rows);
         a.dec_D = d.cout / A; a.dec_rows = d.decode_rows; a.dec_row_offset = hd.row_offset;
         a.dec_stride = hd.stride;
         for (int i = 0; i < A; ++i) { a.dec_aw[i] = hd.anchor_w[i]; a.dec_ah[i] = hd.anchor_h[i]; }
@@ -1742,33 +1833,19 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     a.tiles_n = d.cout_pad / BN;
     a.divHoWo = make_fastdiv((uint32_t)(Ho * Wo));
     a.divWo = make_fastdiv((uint32_t)Wo);
-    // Defaults from A/B timing on MI355X (tools/conv_bench.py): a two-stage ring
-    // with three or four resident workgroups per CU beats deeper rings at one
-    // workgroup per CU on every layer shape of the network.
-    const int ns = env_int("YOLO_AMD_CONV_NSTAGE", 2);
-    // two-step activation tile (whole 128-byte lines per pixel): needs both
-    // sources in whole 64-channel groups; not worth it for the shortest K loops
-    const int amul = env_int("YOLO_AMD_CONV_AMUL", K >= 256 ? 2 : 1);
 
-    // Split reduction (see conv_splitk_finish_kernel): when the caller lent a
-    // workspace and the layer has too few output tiles to occupy the chip.
     a.ksplit = 0; a.kslices = 1;
     FinishArgs f{};
-    if (d.splitk_ws) {
-        int steps, slices;
-        splitk_for(d, &steps, &slices);
-        if (slices > 1 && (size_t)slices * (size_t)M * d.cout * sizeof(float) <= d.splitk_ws_bytes) {
-            YA_REQUIRE(((uintptr_t)d.splitk_ws & 15) == 0, "conv: split-K workspace must be 16-byte aligned");
-            f.partial = (const float*)d.splitk_ws; f.bias = a.bias; f.res = a.res; f.dst = a.dst;
-            f.M = a.M; f.Cout = a.Cout; f.slices = slices; f.leaky = a.leaky; f.dst_fp32 = a.dst_fp32;
-            f.HoWo = Ho * Wo; f.Wo = Wo;
-            f.divCout = make_fastdiv((uint32_t)a.Cout); f.divHoWo = a.divHoWo; f.divWo = a.divWo; f.divD = a.divD;
-            f.dec_D = a.dec_D; f.dec_rows = a.dec_rows; f.dec_row_offset = a.dec_row_offset;
-            f.dec_stride = a.dec_stride;
-            for (int i = 0; i < YOLO_AMD_MAX_ANCHORS; ++i) { f.dec_aw[i] = a.dec_aw[i]; f.dec_ah[i] = a.dec_ah[i]; }
-            a.ksplit = steps; a.kslices = slices;
-            a.dst = d.splitk_ws; a.dst_fp32 = 1; a.res = nullptr; a.leaky = 0; a.dec_D = 0;
-        }
+    if (c.kslices > 1) {
+        f.partial = (const float*)d.splitk_ws; f.bias = a.bias; f.res = a.res; f.dst = a.dst;
+        f.M = a.M; f.Cout = a.Cout; f.slices = c.kslices; f.leaky = a.leaky; f.dst_fp32 = a.dst_fp32;
+        f.HoWo = Ho * Wo; f.Wo = Wo;
+        f.divCout = make_fastdiv((uint32_t)a.Cout); f.divHoWo = a.divHoWo; f.divWo = a.divWo; f.divD = a.divD;
+        f.dec_D = a.dec_D; f.dec_rows = a.dec_rows; f.dec_row_offset = a.dec_row_offset;
+        f.dec_stride = a.dec_stride;
+        for (int i = 0; i < YOLO_AMD_MAX_ANCHORS; ++i) { f.dec_aw[i] = a.dec_aw[i]; f.dec_ah[i] = a.dec_ah[i]; }
+        a.ksplit = c.ksteps; a.kslices = c.kslices;
+        a.dst = d.splitk_ws; a.dst_fp32 = 1; a.res = nullptr; a.leaky = 0; a.dec_D = 0;
     }
     auto finish = [&]() {
         if (a.kslices > 1) {
@@ -1778,7 +1855,7 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         }
         return YA_OK;
     };
-    if (amul == 2 && BK == 32 && ns == 2 && d.c0 % 64 == 0 && d.c1 % 64 == 0) {
+    if (c.amul == 2) {
         if (BN == 128) launch_igemm<128, 128, 32, 2, 2, 2>(a, stream);
         else if (BN == 64) launch_igemm<128, 64, 32, 2, 2, 2>(a, stream);
         else launch_igemm<128, 32, 32, 4, 2, 2>(a, stream);
@@ -1830,6 +1907,17 @@ extern "C" size_t yolo_amd_conv_splitk_bytes(const yolo_amd_conv_desc* d) {
     splitk_for(*d, &steps, &slices);
     if (slices <= 1) return 0;
     return align_up((size_t)slices * (size_t)out_pixels(*d) * d->cout * sizeof(float), 256);
+}
+
+extern "C" int yolo_amd_conv_query(const yolo_amd_conv_desc* d, yolo_amd_conv_choice* out) {
+    YA_REQUIRE(d && out, "conv_query: null pointer");
+    ConvChoice c;
+    const int rc = choose_conv(*d, false, &c);
+    if (rc != YA_OK) return rc;
+    out->kernel = c.kernel; out->bm = c.bm; out->bn = c.bn; out->bk = c.bk;
+    out->act_ksteps = c.amul; out->lds_stages = c.nstage; out->waves = c.waves;
+    out->taps_per_stage = c.stg; out->k_slices = c.kslices;
+    return YA_OK;
 }
 
 // descs[0] (first layer, fuse_next set) and descs[1] as one launch

@@ -32,9 +32,13 @@ class UnsupportedGraph(NotImplementedError):
     pass
 
 
-def graph_from_blocks(blocks, channels, num_classes, num_anchors,
-                      detection_layers=(81, 93, 105)):
-    """Per-block table: type, shapes-independent attributes, absolute sources."""
+def graph_from_blocks(blocks, channels, num_classes, num_anchors, detection_layers=()):
+    """Per-block table: type, shapes-independent attributes, absolute sources.
+
+    A convolution's width is its block's ``filters``.  The model constructor has
+    already rewritten that entry for the caller's detection layers
+    (/root/reference/yolo_v3.py:24-26); for blocks that come straight from a cfg,
+    ``detection_layers`` names the blocks to widen to (num_classes + 5) * num_anchors."""
     det = (num_classes + 5) * num_anchors
     table, out_ch = [], []
     cin = channels
@@ -342,6 +346,9 @@ class Plan:
             conv = seq[0]
             w = conv.weight.detach().float()
             cout = w.shape[0]
+            if cout != ent["cout"] or w.shape[1] != ent["cin"] or w.shape[2] != ent["k"]:
+                raise _lib.YoloAmdError(f"block {i}: the module holds a {tuple(w.shape)} convolution, the plan "
+                                        f"was laid out for {ent['cout']}x{ent['cin']}x{ent['k']}x{ent['k']}")
             if ent["bn"]:
                 bn = seq[1]
                 scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)

@@ -169,9 +169,13 @@ class DetectionPipeline:
             ...
         last = pipe.flush()
 
-    The (K, 9) tensor handed out is a view of one of two internal buffers: it stays
-    valid until the second submit() after it was returned; clone it to keep it longer.
+    The (K, 9) tensor handed out is a view of one of three internal row buffers used in
+    turn: it stays valid until the second submit() after the one that returned it; clone
+    it to keep it longer.  Batches may differ in shape (the last, partial batch of a
+    loader): the pending result is collected before the buffers are replaced.
     """
+
+    SLOTS = 3
 
     def __init__(self, model, params):
         _lib.require_gpu()
@@ -179,28 +183,34 @@ class DetectionPipeline:
         self.device = next(model.parameters()).device
         self.side = torch.cuda.Stream(device=self.device)
         self._slot = 0
-        self._pending = None            # (slot, event) of the batch whose NMS is in flight
+        self._pending = None            # (rows, host count, event) of the batch whose NMS is in flight
         self._bufs = None
 
     def _alloc(self, B, N, C):
+        """Buffers for this batch shape.  Only called with no NMS in flight (submit
+        collects the pending one first), so replacing them never pulls memory from under
+        a running kernel; they are used on the side stream only, which record_stream
+        tells the allocator."""
         if self._bufs is None or self._bufs["shape"] != (B, N, C):
             nbytes = lib.yolo_amd_filter_results_workspace_bytes(B, N, C)
             self._bufs = dict(
                 shape=(B, N, C),
                 ws=torch.empty(nbytes, dtype=torch.uint8, device=self.device),
-                rows=[torch.empty((B * N, 9), dtype=torch.float32, device=self.device) for _ in range(2)],
-                cnt=[torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(2)],
-                host=[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)])
+                rows=[torch.empty((B * N, 9), dtype=torch.float32, device=self.device) for _ in range(self.SLOTS)],
+                cnt=[torch.zeros(1, dtype=torch.int32, device=self.device) for _ in range(self.SLOTS)],
+                host=[torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(self.SLOTS)])
+            for t in [self._bufs["ws"]] + self._bufs["rows"] + self._bufs["cnt"]:
+                t.record_stream(self.side)
         return self._bufs
 
     def _collect(self):
         if self._pending is None:
             return None
-        slot, ev = self._pending
+        rows, host, ev = self._pending
         self._pending = None
         ev.synchronize()
-        k = int(self._bufs["host"][slot].item())
-        return self._bufs["rows"][slot][:k] if k else 0
+        k = int(host.item())
+        return rows[:k] if k else 0
 
     def submit(self, images):
         """Launch forward + NMS for `images`; returns the finished output of the batch
@@ -209,22 +219,23 @@ class DetectionPipeline:
         pred = self.model(images)                       # forward of this batch: overlaps the pending NMS
         B, N, D = pred.shape
         C = int(self.params["num_classes"])
-        bufs = self._alloc(B, N, C)
-        previous = self._collect()                      # also frees the workspace for this batch's NMS
+        previous = self._collect()                      # the pending NMS is done: its workspace is free,
+        bufs = self._alloc(B, N, C)                     # ... and the buffers may be replaced on a shape change
         slot = self._slot
-        self._slot ^= 1
+        self._slot = (self._slot + 1) % self.SLOTS
         self.side.wait_stream(main)
         pred.record_stream(self.side)
+        rows, cnt, host = bufs["rows"][slot], bufs["cnt"][slot], bufs["host"][slot]
         with torch.cuda.device(self.device), torch.cuda.stream(self.side):
             check(lib.yolo_amd_filter_results(pred.data_ptr(), B, N, D, C, float(self.params["confidence"]),
                                               float(self.params["nms_thesh"]), bufs["ws"].data_ptr(),
-                                              bufs["ws"].numel(), bufs["rows"][slot].data_ptr(),
-                                              bufs["cnt"][slot].data_ptr(), self.side.cuda_stream),
+                                              bufs["ws"].numel(), rows.data_ptr(), cnt.data_ptr(),
+                                              self.side.cuda_stream),
                   "filter_results")
-            bufs["host"][slot].copy_(bufs["cnt"][slot], non_blocking=True)
+            host.copy_(cnt, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.side)
-        self._pending = (slot, ev)
+        self._pending = (rows, host, ev)
         return previous
 
     def flush(self):

@@ -8,7 +8,8 @@ for what detection.py, video.py, get_fps.py and evaluate.py import:
   graph construction:      parse_cfg, create_module, empty_layer, yolo_layer
   small host helpers:      load_classes, compute_ap, my_collate,
                            my_collate_detection, worker_init_fn,
-                           ImgToTensorCv, _save_checkpoint, prep_params
+                           ImgToTensorCv, _save_checkpoint, prep_params,
+                           prep_labels
   cv2-dependent helpers:   LetterBoxImage_cv, LetterboxImage, letterbox_image,
                            prep_image, write, detection_write (import cv2 lazily)
 
@@ -175,7 +176,12 @@ _WORKSPACES = {}
 
 
 def _workspace(device, nbytes):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch for the NMS kernels, one buffer per (device, stream): calls queued on
+    one stream run in order and may share it, calls on different streams may overlap
+    and must not.  A buffer that is outgrown is replaced; the caching allocator keeps
+    the old block intact until the kernels already queued on its stream have run."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(device).cuda_stream)
     buf = _WORKSPACES.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
@@ -234,22 +240,16 @@ def filter_img_class(cls, image_pred, ind, nms_thesh):
     return res if dev.type == "cuda" else tuple(r.to(dev) for r in res)
 
 
-def filter_results(prediction, params):
-    """Confidence filter + per-(image, class) NMS
-    (/root/reference/utilis.py:393-465).
-
-    prediction: (B, N, 5+C) decoded boxes; never modified.  Returns a (K, 9)
-    fp32 tensor [image, x1, y1, x2, y2, objectness, class score, class index,
-    ymin] ordered image asc / class asc / objectness desc (ties by original
-    row), or the Python int 0 when nothing passes the confidence threshold.
-    """
+def _launch_filter_results(prediction, params):
+    """Queue the NMS kernels on the current stream.  Returns (rows buffer, device
+    count, source device), or None for an empty input."""
     pred, dev = _to_device_f32(prediction)
     if pred.dim() != 3:
         raise IndexError(f"prediction must be (B, N, 5+C), got {tuple(pred.shape)}")
     B, N, D = pred.shape
     C = int(params["num_classes"])
     if B == 0 or N == 0:
-        return 0
+        return None
     out = torch.empty((B * N, 9), dtype=torch.float32, device=pred.device)
     cnt = torch.empty(1, dtype=torch.int32, device=pred.device)
     nbytes = lib.yolo_amd_filter_results_workspace_bytes(B, N, C)
@@ -260,11 +260,72 @@ def filter_results(prediction, params):
                                           ws.data_ptr(), ws.numel(), out.data_ptr(), cnt.data_ptr(),
                                           _lib.current_stream_ptr(pred.device)),
               "filter_results")
+    return out, cnt, dev
+
+
+def filter_results(prediction, params):
+    """Confidence filter + per-(image, class) NMS
+    (/root/reference/utilis.py:393-465).
+
+    prediction: (B, N, 5+C) decoded boxes; never modified.  Returns a (K, 9)
+    fp32 tensor [image, x1, y1, x2, y2, objectness, class score, class index,
+    ymin] ordered image asc / class asc / objectness desc (ties by original
+    row), or the Python int 0 when nothing passes the confidence threshold.
+    """
+    launched = _launch_filter_results(prediction, params)
+    if launched is None:
+        return 0
+    out, cnt, dev = launched
     k = int(cnt.item())          # the one host read the API needs: callers index output.shape[0]
     if k == 0:
         return 0
     res = out[:k]
     return res if dev.type == "cuda" else res.to(dev)
+
+
+class PendingDetections:
+    """What filter_results_async returns: the NMS is queued, nothing has been waited
+    for.  result() blocks until the row count has reached the host and returns what
+    filter_results would have returned."""
+
+    def __init__(self, rows, host_count, event, dev):
+        self._rows, self._host, self._event, self._dev = rows, host_count, event, dev
+
+    def done(self):
+        return self._event is None or self._event.query()
+
+    def result(self):
+        if self._rows is None:
+            return 0
+        self._event.synchronize()
+        k = int(self._host[0])
+        _PINNED_COUNTS.append(self._host)
+        self._host = None
+        res = self._rows[:k] if k else 0
+        self._rows = None
+        if isinstance(res, int) or self._dev.type == "cuda":
+            return res
+        return res.to(self._dev)
+
+
+_PINNED_COUNTS = []          # recycled pinned host counters (pinning memory is slow)
+
+
+def filter_results_async(prediction, params):
+    """filter_results without the host synchronisation: the kernels and the copy of
+    the row count into pinned host memory are queued on the current stream and a
+    PendingDetections is returned at once, so a caller can queue the next batch's
+    forward pass (or another stream's NMS) before it asks for result().  No
+    counterpart in the reference, whose filter_results is synchronous."""
+    launched = _launch_filter_results(prediction, params)
+    if launched is None:
+        return PendingDetections(None, None, None, None)
+    out, cnt, dev = launched
+    host = _PINNED_COUNTS.pop() if _PINNED_COUNTS else torch.zeros(1, dtype=torch.int32).pin_memory()
+    host.copy_(cnt, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record(torch.cuda.current_stream(out.device))
+    return PendingDetections(out, host, event, dev)
 
 
 def predict_transform(prediction, inp_dim, anchors, num_classes, CUDA=True):
@@ -420,12 +481,33 @@ def _save_checkpoint(model, save_txt=True):
             fh.write(json.dumps(dump, indent=4))
 
 
+def prep_labels(img_txt_path, name_list, label_csv_mame, selected_cls=False):
+    """Collect Darknet label files into one csv (/root/reference/utilis.py:519-535):
+    every line of every file matching the glob ``img_txt_path`` becomes a row whose
+    first column is the file's path with 'txt' replaced by 'jpg' (every occurrence,
+    as str.replace does) and whose other columns are the line's whitespace-separated
+    items, kept as strings; ``selected_cls`` keeps the rows whose column ``c`` is in
+    the list."""
+    import glob
+    import pandas as pd
+    rows = []
+    for path in glob.glob(img_txt_path):
+        with open(path, "r") as fh:
+            for line in fh:
+                items = line.split()
+                rows.append([path.replace("txt", "jpg")] + [items[i - 1] for i in range(1, len(name_list))])
+    out_file = pd.DataFrame(rows, columns=name_list)
+    if selected_cls:
+        out_file = out_file[out_file.c.isin(selected_cls)]
+    out_file.to_csv(label_csv_mame, index=False)
+
+
 def prep_params(params_dir, label_csv_mame, experiment_params=False,
                 names_file="../4Others/human_eye.names"):
     """Load the params JSON, merge overrides, turn the anchor list into an
-    array and add 'classes' and 'conf_list' (/root/reference/utilis.py:673-690).
-    Anchors that are not a list would need the reference's k-means over a
-    label csv, which is outside this package."""
+    array -- or, when the file holds no list, run the anchor k-means over the
+    label csv with num_anchors * 3 clusters -- and add 'classes' and
+    'conf_list' (/root/reference/utilis.py:673-690)."""
     with open(params_dir) as fh:
         params = json.load(fh)
     if experiment_params:
@@ -434,8 +516,10 @@ def prep_params(params_dir, label_csv_mame, experiment_params=False,
     if type(params["anchors"]) == list:
         params["anchors"] = np.array(params["anchors"])
     else:
-        raise NotImplementedError("anchors must be a list in the params file; anchor k-means "
-                                  "(generate_anchors.py) is not part of this package")
+        from .generate_anchors import generate_anchor
+        params["anchors"] = generate_anchor(label_csv_mame, params["width"], params["height"],
+                                            num_clusters=params["num_anchors"] * 3)
     params["classes"] = load_classes(names_file)
     params["conf_list"] = list(np.arange(start=0.2, stop=0.95, step=0.025))
+    print(params)
     return params

@@ -107,7 +107,12 @@ class yolo_v3(nn.Module):
         self._invalidate()
 
     def _plan(self, B, H):
-        key = (B, H)
+        # One plan (activation arena, split-K scratch, descriptors) per shape AND per
+        # stream: calls queued on one stream run in order and share it, calls on two
+        # streams may overlap on the GPU and get arenas of their own.
+        dev = next(self.parameters()).device
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        key = (B, H, stream)
         plan = self._plans.get(key)
         if plan is None:
             plan = Plan(self, B, H)
