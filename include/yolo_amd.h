@@ -83,6 +83,23 @@ int yolo_amd_filter_results(const float* pred, int B, int N, int D, int C, float
                             float nms_thresh, void* workspace, size_t workspace_bytes,
                             float* out_rows, int* out_count, void* stream);
 
+/* yolo_amd_filter_results without a workspace argument, for callers that cannot
+ * allocate device memory (code under HIP graph capture, serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  The
+ * workspace is a static device array of YOLO_AMD_STATIC_SCRATCH_BYTES inside
+ * the library (each GPU the library runs on holds one copy until the process
+ * ends); shapes whose yolo_amd_filter_results_workspace_bytes(B, N, C) exceeds
+ * it are rejected with a negative code and a message (16 MiB covers one 416 or
+ * 320 image, two 416 images at C = 80, not a 608 image).  The call itself
+ * allocates and frees nothing; the first call on a device looks up the array's
+ * address (hipGetSymbolAddress) -- make that call outside a graph capture.
+ * Same kernels, same rows, bit for bit, as yolo_amd_filter_results.
+ * Every call on one GPU uses that GPU's one array: calls that overlap in time
+ * on one GPU (two streams) race; queue them on one stream. */
+#define YOLO_AMD_STATIC_SCRATCH_BYTES (16u << 20)
+int yolo_amd_filter_results_static(const float* pred, int B, int N, int D, int C, float conf,
+                                   float nms_thresh, float* out_rows, int* out_count, void* stream);
+
 /* Replaces utilis.filter_img_class(cls, image_pred, ind, nms_thesh)
  *                                         /root/reference/utilis.py:355-390
  * rows8: (m, 8) fp32 [x1, y1, x2, y2, objectness, class score, class index,

@@ -89,6 +89,10 @@ SYMBOLS = {
                                                 ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                 ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "yolo_amd_filter_results_static": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                       ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                                       ctypes.c_void_p]),
     "yolo_amd_filter_img_class_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int]),
     "yolo_amd_filter_img_class": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                   ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,

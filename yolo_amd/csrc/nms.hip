@@ -25,6 +25,8 @@
 // All arithmetic that decides a keep/suppress outcome is plain IEEE fp32 with
 // no contraction (the file is built with -ffp-contract=off) and correctly
 // rounded division, so kept rows are bit-identical to the reference's.
+#include <mutex>
+
 #include "common.h"
 #include "../../include/yolo_amd.h"
 
@@ -637,10 +639,11 @@ extern "C" size_t yolo_amd_filter_results_workspace_bytes(int B, int N, int C) {
     return carve(nullptr, B, N, C).bytes;
 }
 
-extern "C" int yolo_amd_filter_results(const float* pred, int B, int N, int D, int C, float conf,
-                                       float nms_thresh, void* workspace, size_t workspace_bytes,
-                                       float* out_rows, int* out_count, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+// The kernels of filter_results on a workspace the caller of this function
+// provides (the library user's buffer, or this library's static scratch).
+static int run_filter_results(const float* pred, int B, int N, int D, int C, float conf, float nms_thresh,
+                              void* workspace, size_t workspace_bytes, float* out_rows, int* out_count,
+                              hipStream_t stream) {
     YA_REQUIRE(pred && workspace && out_rows && out_count, "filter_results: null pointer");
     YA_REQUIRE(B > 0 && N > 0 && C > 0, "filter_results: B, N, C must be positive (got %d, %d, %d)", B, N, C);
     YA_REQUIRE(D >= 5 + C, "filter_results: D=%d is smaller than 5 + C=%d", D, 5 + C);
@@ -684,6 +687,56 @@ extern "C" int yolo_amd_filter_results(const float* pred, int B, int N, int D, i
                        w.seg_start, w.seg_kept, w.seg_off, w.kept_pos, w.boxes, w.scores, out_rows);
     YA_CHECK_HIP(hipGetLastError());
     return YA_OK;
+}
+
+extern "C" int yolo_amd_filter_results(const float* pred, int B, int N, int D, int C, float conf,
+                                       float nms_thresh, void* workspace, size_t workspace_bytes,
+                                       float* out_rows, int* out_count, void* stream_) {
+    return run_filter_results(pred, B, N, D, C, conf, nms_thresh, workspace, workspace_bytes, out_rows,
+                              out_count, (hipStream_t)stream_);
+}
+
+// ---------------------------------------------------------------- filter_results without a caller workspace
+// For callers that cannot allocate (code under HIP graph capture, tight serving
+// loops): the workspace of filter_results lives in a file-scope device array
+// that every GPU the library runs on holds until the process ends.  In host
+// code the array's name is only a stand-in for the symbol, not a device address:
+// the address on a device comes from hipGetSymbolAddress, taken once per device
+// with that device current, and only that pointer is ever handed to a kernel
+// or to hipMemsetAsync.
+static __device__ __align__(256) unsigned char scratch[YOLO_AMD_STATIC_SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+static void* g_scratch_ptr[MAX_DEVICES];           // per device: where `scratch` lives there
+static std::mutex g_scratch_mutex;
+
+extern "C" int yolo_amd_filter_results_static(const float* pred, int B, int N, int D, int C, float conf,
+                                              float nms_thresh, float* out_rows, int* out_count,
+                                              void* stream_) {
+    YA_REQUIRE(B > 0 && N > 0 && C > 0, "filter_results_static: B, N, C must be positive (got %d, %d, %d)", B, N, C);
+    const size_t need = carve(nullptr, B, N, C).bytes;
+    if (need > (size_t)YOLO_AMD_STATIC_SCRATCH_BYTES) {
+        set_error("filter_results_static: B=%d, N=%d, C=%d needs %zu bytes of workspace, the static scratch holds "
+                  "%zu; use yolo_amd_filter_results with a caller workspace", B, N, C, need,
+                  (size_t)YOLO_AMD_STATIC_SCRATCH_BYTES);
+        return YA_ERR_WORKSPACE;
+    }
+    int dev = -1;
+    YA_CHECK_HIP(hipGetDevice(&dev));
+    YA_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "filter_results_static: device %d out of range", dev);
+    void* ptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        if (!g_scratch_ptr[dev]) {
+            void* p = nullptr;
+            YA_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            YA_REQUIRE(p && ((uintptr_t)p & 255) == 0, "filter_results_static: bad address for the static scratch");
+            g_scratch_ptr[dev] = p;
+        }
+        ptr = g_scratch_ptr[dev];
+    }
+    return run_filter_results(pred, B, N, D, C, conf, nms_thresh, ptr, (size_t)YOLO_AMD_STATIC_SCRATCH_BYTES,
+                              out_rows, out_count, (hipStream_t)stream_);
 }
 
 
