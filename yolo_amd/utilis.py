@@ -240,8 +240,51 @@ def filter_img_class(cls, image_pred, ind, nms_thesh):
     return res if dev.type == "cuda" else tuple(r.to(dev) for r in res)
 
 
+class _HostCount:
+    """A pinned host int32 the scan kernel writes the row count K into directly (pinned
+    memory is mapped into the device's address space), so that no copy kernel and no
+    stream synchronisation stand between the last NMS kernel and the host knowing K.
+    The host arms it with -1 and polls; counters are recycled (pinning is slow)."""
+    _pool = []
+
+    def __init__(self):
+        self.tensor = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.view = self.tensor.numpy()
+
+    @classmethod
+    def take(cls):
+        hc = cls._pool.pop() if cls._pool else cls()
+        hc.view[0] = -1
+        hc.stream = None
+        return hc
+
+    def give_back(self):
+        _HostCount._pool.append(self)
+
+    def ready(self):
+        return int(self.view[0]) != -1
+
+    def wait(self):
+        """Spin until the kernel has stored K (a few microseconds after the scan kernel
+        ends).  Every few dozen polls the stream is queried as well: once everything
+        queued has run, a synchronisation makes the store visible whatever the memory's
+        coherence mode -- and surfaces a failed kernel instead of spinning for ever."""
+        view = self.view
+        stream = self.stream                 # the stream the kernels were queued on
+        while True:
+            for _ in range(256):
+                if view[0] != -1:
+                    return int(view[0])
+            if stream.query():
+                break
+        stream.synchronize()
+        if view[0] == -1:
+            raise _lib.YoloAmdError("filter_results: the row count never reached the host")
+        return int(view[0])
+
+
 def _launch_filter_results(prediction, params):
-    """Queue the NMS kernels on the current stream.  Returns (rows buffer, device
+    """Queue the NMS kernels on the current stream.  Returns (rows buffer, host
     count, source device), or None for an empty input."""
     pred, dev = _to_device_f32(prediction)
     if pred.dim() != 3:
@@ -251,13 +294,14 @@ def _launch_filter_results(prediction, params):
     if B == 0 or N == 0:
         return None
     out = torch.empty((B * N, 9), dtype=torch.float32, device=pred.device)
-    cnt = torch.empty(1, dtype=torch.int32, device=pred.device)
     nbytes = lib.yolo_amd_filter_results_workspace_bytes(B, N, C)
     ws = _workspace(pred.device, nbytes)
+    cnt = _HostCount.take()
+    cnt.stream = torch.cuda.current_stream(pred.device)
     with torch.cuda.device(pred.device):
         check(lib.yolo_amd_filter_results(pred.data_ptr(), B, N, D, C,
                                           float(params["confidence"]), float(params["nms_thesh"]),
-                                          ws.data_ptr(), ws.numel(), out.data_ptr(), cnt.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), out.data_ptr(), cnt.tensor.data_ptr(),
                                           _lib.current_stream_ptr(pred.device)),
               "filter_results")
     return out, cnt, dev
@@ -271,12 +315,17 @@ def filter_results(prediction, params):
     fp32 tensor [image, x1, y1, x2, y2, objectness, class score, class index,
     ymin] ordered image asc / class asc / objectness desc (ties by original
     row), or the Python int 0 when nothing passes the confidence threshold.
+
+    The row count K is the one thing the host has to wait for (callers index
+    output.shape[0]); the rows themselves are ready in stream order, like any
+    other tensor a kernel has just written.
     """
     launched = _launch_filter_results(prediction, params)
     if launched is None:
         return 0
     out, cnt, dev = launched
-    k = int(cnt.item())          # the one host read the API needs: callers index output.shape[0]
+    k = cnt.wait()
+    cnt.give_back()
     if k == 0:
         return 0
     res = out[:k]
@@ -288,18 +337,17 @@ class PendingDetections:
     for.  result() blocks until the row count has reached the host and returns what
     filter_results would have returned."""
 
-    def __init__(self, rows, host_count, event, dev):
-        self._rows, self._host, self._event, self._dev = rows, host_count, event, dev
+    def __init__(self, rows, host_count, dev):
+        self._rows, self._host, self._dev = rows, host_count, dev
 
     def done(self):
-        return self._event is None or self._event.query()
+        return self._host is None or self._host.ready()
 
     def result(self):
         if self._rows is None:
             return 0
-        self._event.synchronize()
-        k = int(self._host[0])
-        _PINNED_COUNTS.append(self._host)
+        k = self._host.wait()
+        self._host.give_back()
         self._host = None
         res = self._rows[:k] if k else 0
         self._rows = None
@@ -308,24 +356,16 @@ class PendingDetections:
         return res.to(self._dev)
 
 
-_PINNED_COUNTS = []          # recycled pinned host counters (pinning memory is slow)
-
-
 def filter_results_async(prediction, params):
-    """filter_results without the host synchronisation: the kernels and the copy of
-    the row count into pinned host memory are queued on the current stream and a
-    PendingDetections is returned at once, so a caller can queue the next batch's
-    forward pass (or another stream's NMS) before it asks for result().  No
-    counterpart in the reference, whose filter_results is synchronous."""
+    """filter_results without the wait: the kernels are queued on the current stream
+    and a PendingDetections is returned at once, so a caller can queue the next batch's
+    forward pass (or another stream's NMS) before it asks for result().  No counterpart
+    in the reference, whose filter_results is synchronous."""
     launched = _launch_filter_results(prediction, params)
     if launched is None:
-        return PendingDetections(None, None, None, None)
+        return PendingDetections(None, None, None)
     out, cnt, dev = launched
-    host = _PINNED_COUNTS.pop() if _PINNED_COUNTS else torch.zeros(1, dtype=torch.int32).pin_memory()
-    host.copy_(cnt, non_blocking=True)
-    event = torch.cuda.Event()
-    event.record(torch.cuda.current_stream(out.device))
-    return PendingDetections(out, host, event, dev)
+    return PendingDetections(out, cnt, dev)
 
 
 def predict_transform(prediction, inp_dim, anchors, num_classes, CUDA=True):

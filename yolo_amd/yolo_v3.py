@@ -79,6 +79,7 @@ class yolo_v3(nn.Module):
         self.losses_name = ["total_loss", "x", "y", "w", "h", "conf", "cls"]
         self._plans = {}
         self._weights_version = 0
+        self._device = None
         if self.params["pretrain_snapshot"]:
             self.load_state_dict(torch.load(self.params["pretrain_snapshot"]))
         elif weight_file is not None:
@@ -90,6 +91,12 @@ class yolo_v3(nn.Module):
     def _invalidate(self):
         self._plans = {}
         self._weights_version += 1
+        self._device = None               # looked up again at the next forward
+
+    def _param_device(self):
+        if self._device is None:
+            self._device = next(self.parameters()).device
+        return self._device
 
     def load_state_dict(self, *args, **kwargs):
         res = super().load_state_dict(*args, **kwargs)
@@ -110,7 +117,7 @@ class yolo_v3(nn.Module):
         # One plan (activation arena, split-K scratch, descriptors) per shape AND per
         # stream: calls queued on one stream run in order and share it, calls on two
         # streams may overlap on the GPU and get arenas of their own.
-        dev = next(self.parameters()).device
+        dev = self._param_device()
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
         key = (B, H, stream)
         plan = self._plans.get(key)
@@ -135,7 +142,7 @@ class yolo_v3(nn.Module):
         if x.dim() != 4 or x.shape[2] != x.shape[3]:
             raise ValueError("expected a (B, C, H, H) batch")
         src_device = x.device
-        dev = next(self.parameters()).device
+        dev = self._param_device()
         if dev.type != "cuda":
             raise _lib.YoloAmdError("the model is on the CPU: call .cuda() (params['cuda']=True); "
                                     "the fused path has no CPU implementation")
