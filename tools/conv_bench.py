@@ -35,6 +35,8 @@ LAYERS = [
     ("1x1 512->256 @26", 26, 512, 256, 1, 1, False),
     ("1x1 1024->512 @13", 13, 1024, 512, 1, 1, False),
     ("1x1 256->255 @52 fp32", 52, 256, 255, 1, 1, False),
+    ("1x1 512->255 @26 fp32", 26, 512, 255, 1, 1, False),
+    ("1x1 1024->255 @13 fp32", 13, 1024, 255, 1, 1, False),
     # almost no K loop: what a launch costs in set-up, epilogue and tail
     ("ovh 1x1 32->512 @26 res", 26, 32, 512, 1, 1, True),
     ("ovh 1x1 32->512 @26", 26, 32, 512, 1, 1, False),
@@ -78,13 +80,14 @@ def make_desc(B, H, cin, cout, k, stride, residual, dev):
 
 def set_variant(v):
     for key in ("YOLO_AMD_CONV_NSTAGE", "YOLO_AMD_CONV_BK", "YOLO_AMD_CONV_TILE", "YOLO_AMD_CONV3",
-                "YOLO_AMD_CONV_AMUL", "YOLO_AMD_CONV_BN", "YOLO_AMD_CONV3_WAVES", "YOLO_AMD_CONV3_PRIO", "YOLO_AMD_CONV3_STG"):
+                "YOLO_AMD_CONV_AMUL", "YOLO_AMD_CONV_BN", "YOLO_AMD_CONV3_WAVES", "YOLO_AMD_CONV3_PRIO", "YOLO_AMD_CONV3_STG",
+                "YOLO_AMD_CONV_FP32EPI"):
         os.environ.pop(key, None)
     for item in filter(None, v.split(",")):
         k, val = item.split("=")
         os.environ[{"ns": "YOLO_AMD_CONV_NSTAGE", "bk": "YOLO_AMD_CONV_BK",
                     "tile": "YOLO_AMD_CONV_TILE", "p3": "YOLO_AMD_CONV3",
-                    "am": "YOLO_AMD_CONV_AMUL", "bn": "YOLO_AMD_CONV_BN", "p3w": "YOLO_AMD_CONV3_WAVES", "prio": "YOLO_AMD_CONV3_PRIO", "stg": "YOLO_AMD_CONV3_STG"}[k]] = val
+                    "am": "YOLO_AMD_CONV_AMUL", "bn": "YOLO_AMD_CONV_BN", "p3w": "YOLO_AMD_CONV3_WAVES", "prio": "YOLO_AMD_CONV3_PRIO", "stg": "YOLO_AMD_CONV3_STG", "f32": "YOLO_AMD_CONV_FP32EPI"}[k]] = val
 
 
 def apply_variant(v):

@@ -425,9 +425,11 @@ conv_igemm_kernel(const ConvArgs a) {
     if (a.dst_fp32 && !a.res) {
         // fp32 output (the detection convolutions, 255 channels: rows of 1020
         // bytes).  The tile goes through LDS 32 channels at a time so that the
-        // stores are runs of 128 contiguous bytes per pixel, and the head decode
+        // stores are runs of 256 contiguous bytes per pixel, and the head decode
         // (yolo_v3.predict), when asked for, is applied on the way out.
-        constexpr int PC = 32, PITCH = PC + 4;            // +4 floats: the 16 pixel rows of a b128 write hit distinct banks
+        // 64 channels per pass where the operand stages leave that much LDS, else 32
+        constexpr int PC = (BN >= 64 && LDS_BYTES >= BM * (64 + 4) * 4 + BM * 16) ? 64 : 32;
+        constexpr int PITCH = PC + 4;                      // +4 floats: the 16 pixel rows of a b128 write hit distinct banks
         float* const tile = reinterpret_cast<float*>(lds);
         float* const geo = tile + BM * PITCH;              // per tile pixel: destination offset, gx, gy
         __syncthreads();                                   // operand stages are dead from here on
@@ -457,27 +459,26 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll 1
         for (int p = 0; p < BN / PC; ++p) {
             const int c_lo = p * PC;
-            if (wn == c_lo / WNC) {
-                const int tc0 = (c_lo % WNC) / 16;
+            // every wave whose channels fall into this pass parks them (wave-uniform tests)
+            const int wbase = wn * WNC - c_lo;                 // tile column of this wave's first channel
+            if (wbase + WNC > 0 && wbase < PC) {
 #pragma unroll
                 for (int tp = 0; tp < TP; ++tp) {
                     const int slot = wm * WMP + tp * 16 + px;
 #pragma unroll
-                    for (int t = 0; t < PC / 16; ++t) {
-                        f32x4 v = acc[0][tp];
-                        // (static accumulator indices: tc0 is 0 or 2 for 64-channel waves, 0 for 32-channel ones)
-#pragma unroll
-                        for (int tc = 0; tc < TC; ++tc)
-                            if (tc == tc0 + t) v = acc[tc][tp];
+                    for (int tc = 0; tc < TC; ++tc) {
+                        const int col = wbase + tc * 16;
+                        if (col < 0 || col >= PC) continue;
+                        f32x4 v = acc[tc][tp];
                         f32x4 bs = f32x4{0.f, 0.f, 0.f, 0.f};     // partial sums of a split reduction stay raw
-                        if (!a.ksplit) bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + c_lo + t * 16 + cq);
+                        if (!a.ksplit) bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + c_lo + col + cq);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float x = v[r] + bs[r];
                             if (a.leaky) x = x > 0.f ? x : 0.1f * x;
                             v[r] = x;
                         }
-                        *reinterpret_cast<f32x4*>(tile + slot * PITCH + t * 16 + cq) = v;
+                        *reinterpret_cast<f32x4*>(tile + slot * PITCH + col + cq) = v;
                     }
                 }
             }
