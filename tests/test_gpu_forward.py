@@ -236,16 +236,21 @@ PATCH_CASES = [
     ("p3_c256_n512_h26", 2, 26, 256, 512, True, True, False),
     ("p3_c128_n255_fp32", 2, 13, 128, 255, False, False, True),
     ("p3_c64_n128_h52", 1, 52, 64, 128, True, False, False),
+    ("p3_c64_n768_h26_b5", 5, 26, 64, 768, True, True, False),     # three 256-channel tiles, or six of 128
 ]
 
 
-@pytest.mark.parametrize("stg", ["1", "3"], ids=["tap-stages", "row-stages"])
+@pytest.mark.parametrize("stg", ["1", "3", "3/256"], ids=["tap-stages", "row-stages", "row-stages-256ch"])
 @pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: c[0])
 def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     from gpu_helpers import conv_reference, run_conv
     name, B, H, cin, cout, leaky, use_res, fp32_out = case
     set_knob(monkeypatch, "YOLO_AMD_CONV3", "1")
-    set_knob(monkeypatch, "YOLO_AMD_CONV3_STG", stg)
+    wide = stg.endswith("/256")
+    if wide and (cout + 127) // 128 * 128 % 256:
+        pytest.skip("the 256-channel tile needs the padded channel count to be a multiple of 256")
+    set_knob(monkeypatch, "YOLO_AMD_CONV3_STG", stg[0])
+    set_knob(monkeypatch, "YOLO_AMD_CONV3_TC", "4" if wide else "2")
     r = gi.rs(case_seed(name))
     x0 = torch.from_numpy(r.standard_normal((B, H, H, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
     w = torch.from_numpy((r.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
@@ -253,7 +258,10 @@ def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     res = None
     if use_res:
         res = torch.from_numpy(r.standard_normal((B, H, H, cout)).astype(np.float32)).cuda().to(torch.bfloat16)
-    got = run_conv(x0, w, bias, leaky=leaky, residual=res, fp32_out=fp32_out).float().cpu()
+    info = {}
+    got = run_conv(x0, w, bias, leaky=leaky, residual=res, fp32_out=fp32_out, info=info).float().cpu()
+    ch = info["choice"]
+    assert ch["kernel"] == "patch" and ch["bn"] == (256 if wide else 128) and ch["taps_per_stage"] == int(stg[0]), ch
     want = conv_reference(x0, w, bias, leaky=leaky, residual=res)
     assert torch.isfinite(got).all(), "output holds NaN/inf (unwritten elements?)"
     # and the generic im2col kernel must agree with it

@@ -81,13 +81,13 @@ def make_desc(B, H, cin, cout, k, stride, residual, dev):
 def set_variant(v):
     for key in ("YOLO_AMD_CONV_NSTAGE", "YOLO_AMD_CONV_BK", "YOLO_AMD_CONV_TILE", "YOLO_AMD_CONV3",
                 "YOLO_AMD_CONV_AMUL", "YOLO_AMD_CONV_BN", "YOLO_AMD_CONV3_WAVES", "YOLO_AMD_CONV3_PRIO", "YOLO_AMD_CONV3_STG",
-                "YOLO_AMD_CONV_FP32EPI"):
+                "YOLO_AMD_CONV_FP32EPI", "YOLO_AMD_CONV3_TC"):
         os.environ.pop(key, None)
     for item in filter(None, v.split(",")):
         k, val = item.split("=")
         os.environ[{"ns": "YOLO_AMD_CONV_NSTAGE", "bk": "YOLO_AMD_CONV_BK",
                     "tile": "YOLO_AMD_CONV_TILE", "p3": "YOLO_AMD_CONV3",
-                    "am": "YOLO_AMD_CONV_AMUL", "bn": "YOLO_AMD_CONV_BN", "p3w": "YOLO_AMD_CONV3_WAVES", "prio": "YOLO_AMD_CONV3_PRIO", "stg": "YOLO_AMD_CONV3_STG", "f32": "YOLO_AMD_CONV_FP32EPI"}[k]] = val
+                    "am": "YOLO_AMD_CONV_AMUL", "bn": "YOLO_AMD_CONV_BN", "p3w": "YOLO_AMD_CONV3_WAVES", "prio": "YOLO_AMD_CONV3_PRIO", "stg": "YOLO_AMD_CONV3_STG", "f32": "YOLO_AMD_CONV_FP32EPI", "tc": "YOLO_AMD_CONV3_TC"}[k]] = val
 
 
 def apply_variant(v):
@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--variants", default="ns=2;ns=3;ns=4;ns=2,bk=32;ns=4,bk=32;ns=5,bk=32")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--zeros", action="store_true", help="zero-filled operands (a clock probe: no data toggling)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     zero = torch.zeros(1024, dtype=torch.uint8, device=dev)
@@ -111,6 +112,10 @@ def main():
         if args.layers and args.layers not in spec[0]:
             continue
         d, keep, flops, byts = make_desc(args.batch, *spec[1:], dev)
+        if args.zeros:
+            keep[0].zero_(); keep[1].zero_()
+            if keep[4] is not None:
+                keep[4].zero_()
         times = {v: [] for v in variants}
         for rep in range(args.reps + 3):
             for v in variants:

@@ -611,7 +611,6 @@ constexpr int P3_NPIX = P3_TS * P3_TS;     // 169 output pixels per tile
 constexpr int P3_TP = 11;                  // pixel groups of 16 (176 slots)
 constexpr int P3_PLANE = 256 * 16;         // bytes per patch plane (16 rows x 16 slots x 16 B)
 constexpr int P3_PATCH = 4 * P3_PLANE;     // 16 KiB per buffer
-constexpr int P3_WSTAGE = 128 * 64;        // 8 KiB: 128 channels x 32 bf16
 
 struct Conv3Args {
     const __bf16* src;
@@ -636,22 +635,29 @@ struct Conv3Args {
 // whose 13x13 tiles number no more than two per CU.
 // STG = 3 (eight waves): a weight stage is a whole kernel row (three taps, 24 KiB; the ring
 // holds two) and the workgroup meets at a barrier once per row instead of once per tap.
-template <int WAVES, int STG = 1>
-__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 3 : 4, WAVES == 4 ? 3 : 4)))
+// TC = channel groups of 16 per wave: 2 (workgroup = 128 channels) or 4 (256 channels: a wave
+// then issues 24 MFMAs per tap for 6 + 4 fragment reads instead of 12 for 6 + 2; the weight
+// ring grows to 96 KiB, one workgroup of eight waves per CU, up to 256 registers).
+template <int WAVES, int STG = 1, int TC = 2>
+__global__ void __launch_bounds__(64 * WAVES)
+    __attribute__((amdgpu_waves_per_eu(TC == 4 ? 2 : (WAVES == 4 ? 3 : 4), TC == 4 ? 2 : (WAVES == 4 ? 3 : 4))))
 conv3x3_patch_kernel(const Conv3Args a) {
     static_assert(STG == 1 || (STG == 3 && WAVES == 8), "row-deep weight stages exist for the eight-wave form");
+    static_assert(TC == 2 || (TC == 4 && WAVES == 8 && STG == 3), "the 256-channel tile exists for eight waves, row-deep stages");
+    constexpr int CT = 64 * TC;                    // channels per workgroup
+    constexpr int WSTAGE = CT * 64;                // bytes of one (chunk, tap) weight stage: CT channels x 32 bf16
     constexpr int NH = WAVES / 4;                  // waves per channel group
     constexpr int NTP = NH == 1 ? P3_TP : 6;       // pixel groups per wave (upper bound)
     constexpr int PP = 16 / WAVES;                 // patch LDS-DMA instructions per wave per chunk
-    constexpr int WP = 8 / WAVES;                  // weight LDS-DMA instructions per wave per stage
+    constexpr int WP = (CT / 16) / WAVES;          // weight LDS-DMA instructions per wave per stage
     // LDS: weight ring, then the two patch buffers X and Y.  The eight-wave form adds
     // 28 KiB behind Y: Y + that is where the residual tile (176 rows x 256 B = 44 KiB)
     // is parked by LDS-DMA during the LAST chunk, which is made to read buffer X
     // (chunks alternate X/Y counted from the end), so that the residual round trip to
     // memory runs under the matrix work instead of after it.
     constexpr bool RPRE = WAVES == 8 && STG == 1;
-    constexpr int TILE_BYTES = 176 * 256;
-    constexpr int RING_BYTES = 2 * STG * P3_WSTAGE;            // two stages of STG taps
+    constexpr int TILE_BYTES = 176 * CT * 2;
+    constexpr int RING_BYTES = 2 * STG * WSTAGE;            // two stages of STG taps
     __shared__ __attribute__((aligned(1024))) char lds_all[RING_BYTES + 2 * P3_PATCH + (RPRE ? TILE_BYTES - P3_PATCH : 0)];
     static_assert(sizeof(lds_all) >= TILE_BYTES, "the epilogue tile reuses this memory");
     char* const wring = lds_all;
@@ -679,7 +685,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
     }
     const int tile_n = tile % a.tiles_n, gt = tile / a.tiles_n;
-    const int n0 = tile_n * 128;
+    const int n0 = tile_n * CT;
     const int per_img = a.tiles_y * a.tiles_x;
     const int cb = gt / per_img;
     const int oy0 = ((gt - cb * per_img) / a.tiles_x) * P3_TS;
@@ -692,7 +698,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
         const int p = min((tp0 + tp) * 16 + r, P3_NPIX - 1);
         tyb[tp] = q * P3_PLANE + (p / P3_TS) * 256;
     }
-    const int wfrag = (cg * 32) * 64 + slot_of<32>(r, q) * 16;
+    const int wfrag = (cg * 16 * TC) * 64 + slot_of<32>(r, q) * 16;
 
     const int NCH = a.C / 32;
     // ---- patch fill: 16 LDS-DMA instructions of 4 rows each; this wave's are
@@ -716,7 +722,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
         lds_dma16(pp, lds + ((NCH - 1 - chunk) & 1) * P3_PATCH + cg * P3_PLANE + (half * PP + ii) * 1024);
     };
     // ---- weight fill: 8 LDS-DMA instructions per (chunk, tap) stage, WP per wave
-    const int cout_pad = a.tiles_n * 128;
+    const int cout_pad = a.tiles_n * CT;
     int woff[WP];
     {
         const int qw = (lane & 3) ^ chunk_swizzle<32>(lane >> 2);
@@ -729,12 +735,12 @@ conv3x3_patch_kernel(const Conv3Args a) {
         const int delta = tap * wstep_tap + chunk * wstep_chunk;
 #pragma unroll
         for (int i = 0; i < WP; ++i)
-            lds_dma16(a.wgt + (woff[i] + delta), wring + buf * P3_WSTAGE + (w * WP + i) * 1024);
+            lds_dma16(a.wgt + (woff[i] + delta), wring + buf * WSTAGE + (w * WP + i) * 1024);
     };
 
-    f32x4 acc[2][NTP];
+    f32x4 acc[TC][NTP];
 #pragma unroll
-    for (int tc = 0; tc < 2; ++tc)
+    for (int tc = 0; tc < TC; ++tc)
 #pragma unroll
         for (int tp = 0; tp < NTP; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -744,7 +750,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
     stamp(1);
     bool patch_behind = false;                 // a patch load was issued after the weights now awaited
     // the vector epilogue will want the residual tile in LDS (all 128 channels of the tile exist)
-    const bool res_pre = RPRE && (a.prio & 2) && a.res && !a.dst_fp32 && (a.Cout & 7) == 0 && n0 + 128 <= a.Cout;
+    const bool res_pre = RPRE && (a.prio & 2) && a.res && !a.dst_fp32 && (a.Cout & 7) == 0 && n0 + CT <= a.Cout;
     int buf = 0;
     if constexpr (STG == 3) {
         // Ring slots 0-2 and 3-5 hold the three taps of the current and of the next
@@ -769,10 +775,10 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     if (next_row) issue_w(nchunk, ntap0 + kw, (base ^ 3) + kw);
                     if (kh == 0 && kw < PP && more_chunks) issue_patch(chunk + 1, kw);
                     const int colb = ((r + kw + P3_TS * kh) & 15) * 16 + kh * 256;
-                    const char* ws = wring + (base + kw) * P3_WSTAGE + wfrag;
-                    bf16x8 wf[2], xf[6];
+                    const char* ws = wring + (base + kw) * WSTAGE + wfrag;
+                    bf16x8 wf[TC], xf[6];
 #pragma unroll
-                    for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
+                    for (int tc = 0; tc < TC; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
 #pragma unroll
                     for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
                     if (a.prio & 1) __builtin_amdgcn_s_setprio(2);
@@ -780,7 +786,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     for (int tp = 0; tp < 6; ++tp) {
                         if (tp == 5 && ntp == 5) break;                 // the second half has five groups
 #pragma unroll
-                        for (int tc = 0; tc < 2; ++tc)
+                        for (int tc = 0; tc < TC; ++tc)
                             acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
                     }
                     if (a.prio & 1) __builtin_amdgcn_s_setprio(0);
@@ -823,10 +829,10 @@ conv3x3_patch_kernel(const Conv3Args a) {
             }
 
             const int colb = ((r + kw + P3_TS * kh) & 15) * 16 + kh * 256;
-            const char* ws = wring + buf * P3_WSTAGE + wfrag;
-            bf16x8 wf[2];
+            const char* ws = wring + buf * WSTAGE + wfrag;
+            bf16x8 wf[TC];
 #pragma unroll
-            for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
+            for (int tc = 0; tc < TC; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
             {
                 bf16x8 xf[6];
 #pragma unroll
@@ -836,7 +842,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 for (int tp = 0; tp < 6; ++tp) {
                     if (NH == 2 && tp == 5 && ntp == 5) break;          // the second half has five groups
 #pragma unroll
-                    for (int tc = 0; tc < 2; ++tc)
+                    for (int tc = 0; tc < TC; ++tc)
                         acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
                 }
             }
@@ -848,7 +854,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
                 for (int tp = 0; tp < 5; ++tp)
 #pragma unroll
-                    for (int tc = 0; tc < 2; ++tc)
+                    for (int tc = 0; tc < TC; ++tc)
                         acc[tc][6 + tp] =
                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][6 + tp], 0, 0, 0);
             }
@@ -871,7 +877,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
         wait_vmcnt<0>();
         __syncthreads();
         if (a.res && !res_pre) {
-            tile_load_residual<NSLOT, 128, 64 * WAVES>(rtile, a.res, a.zero, a.Cout, n0, w, lane, pix);
+            tile_load_residual<NSLOT, CT, 64 * WAVES>(rtile, a.res, a.zero, a.Cout, n0, w, lane, pix);
             __syncthreads();
         }
 #pragma unroll
@@ -879,8 +885,8 @@ conv3x3_patch_kernel(const Conv3Args a) {
             if (tp >= ntp) break;
             const int slot = (tp0 + tp) * 16 + r;
 #pragma unroll
-            for (int tc = 0; tc < 2; ++tc) {
-                const int chl = cg * 32 + tc * 16 + cq;
+            for (int tc = 0; tc < TC; ++tc) {
+                const int chl = cg * 16 * TC + tc * 16 + cq;
                 const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + chl);
                 float v[4];
 #pragma unroll
@@ -889,11 +895,11 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     if (a.leaky) x = x > 0.f ? x : 0.1f * x;
                     v[e] = x;
                 }
-                tile_put<128>(rtile, slot, chl, v, a.res != nullptr);
+                tile_put<CT>(rtile, slot, chl, v, a.res != nullptr);
             }
         }
         __syncthreads();
-        tile_store<NSLOT, 128, 64 * WAVES>(rtile, (__bf16*)a.dst, a.Cout, n0, pix);
+        tile_store<NSLOT, CT, 64 * WAVES>(rtile, (__bf16*)a.dst, a.Cout, n0, pix);
         stamp(3);
         return;
     }
@@ -904,8 +910,8 @@ conv3x3_patch_kernel(const Conv3Args a) {
         const int ty = p / P3_TS, tx = p - ty * P3_TS;
         const size_t m = ((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
 #pragma unroll
-        for (int tc = 0; tc < 2; ++tc) {
-            const int ch = n0 + cg * 32 + tc * 16 + cq;
+        for (int tc = 0; tc < TC; ++tc) {
+            const int ch = n0 + cg * 16 * TC + tc * 16 + cq;
             if (ch >= a.Cout) continue;
             const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + ch);
             const size_t o = m * a.Cout + ch;
@@ -1721,6 +1727,12 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
         c.stg = env_int("YOLO_AMD_CONV3_STG", 3) == 3 ? 3 : 1;
         c.waves = env_int("YOLO_AMD_CONV3_WAVES", (c.stg == 3 || p3_groups <= 1536) ? 8 : 4) == 8 ? 8 : 4;
         if (c.waves == 4) c.stg = 1;
+        // 256-channel workgroups (one per CU, 24 MFMAs per 10 fragment reads instead of 12 per 8):
+        // measured no faster on 26x26 (55.4 against 56.5 us) and slower on 52x52 and 13x13
+        // (66.7 against 61.4, 81 against 61 us), so only YOLO_AMD_CONV3_TC=4 selects them
+        // (development knob; the variant stays under test)
+        if (c.waves == 8 && c.stg == 3 && d.cout_pad % 256 == 0 && env_int("YOLO_AMD_CONV3_TC", 2) == 4)
+            c.bn = 256;
         *out = c;
         return YA_OK;
     }
@@ -1797,13 +1809,15 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.res = (const __bf16*)d.residual; p.dst = d.dst; p.zero = (const __bf16*)zero_page;
         p.C = d.c0; p.H = d.H; p.W = d.W; p.Cout = d.cout; p.K = K; p.leaky = d.leaky; p.dst_fp32 = d.dst_fp32;
         p.tiles_y = d.H / P3_TS; p.tiles_x = d.W / P3_TS; p.ntiles = d.B * p.tiles_y * p.tiles_x;
-        p.tiles_n = d.cout_pad / 128;
+        p.tiles_n = d.cout_pad / c.bn;
         p.prio = env_int("YOLO_AMD_CONV3_PRIO", 3);
         p.trace = nullptr;
 #ifdef YOLO_AMD_DEV_TRACE
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
 #endif
-        if (c.waves == 8 && c.stg == 3)
+        if (c.bn == 256)
+            hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3, 4>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.waves == 8 && c.stg == 3)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.waves == 8)
             hipLaunchKernelGGL(conv3x3_patch_kernel<8>, dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
