@@ -402,33 +402,49 @@ nms_mask_kernel(const unsigned long long* __restrict__ keys, int key_stride, int
 }
 
 // ---------------------------------------------------------------- reduce
-// One workgroup (4 waves) per (image, class).  `removed` holds one bit per box
-// of the segment.  For each group g of 64 boxes in visiting order, wave 0
-// resolves the group with its diagonal tile: a box survives iff its bit is
-// still clear, and then sets the bits of the boxes it suppresses inside the
-// group.  Only boxes that suppress something take a serial step (a box with an
-// empty word changes nothing), so a group without overlaps costs no loop at
-// all.  Then wave w takes the later groups' words w, w+4, ...: lane = box of
-// group g reads its word of tile (g, word), the survivors' words are OR-ed
-// across the wave and the result is merged into `removed`.  A box survives iff
-// `iou < thresh` held against every earlier survivor: the reference's greedy
-// loop (utilis.py:367-385).
+// One workgroup (8 waves) per (image, class).  For each group g of 64 boxes in
+// visiting order a box survives iff no earlier survivor suppresses it (the
+// reference's greedy loop, utilis.py:367-385): `removed` bit of box j = OR over the
+// earlier survivors i of bit j of i's mask row.
+//
+// Wave 0 walks the chain.  At step g it owns the group's removed word, resolves
+// the group with its diagonal tile (serial only over boxes that suppress
+// something: a box with an empty word changes nothing), writes the survivors'
+// positions, and folds the survivors' rows of tile (g, g+1) -- the only tile the
+// NEXT step depends on, fetched a step ahead -- into a register it carries over.
+// Waves 1-7 run one step behind: they fold the survivors of group g-1 into the
+// words g+1, g+2, ... (several tile loads in flight per wave), which nobody needs
+// before step g+1.  One barrier per step; the chain's step is a resolve plus one
+// wave-wide OR instead of a resolve plus a round of dependent tile loads.
 constexpr int REDUCE_MAX_WORDS = 512;    // 32768 boxes per segment
+constexpr int REDUCE_THREADS = 512;
 
+// OR over the 64 lanes, the same value in every lane afterwards.  Four DPP steps
+// (row_shr 1, 2, 4, 8: lanes shifted in from outside a row of 16 read as zero) leave
+// the OR of each row in its last lane, four v_readlane fetch those into scalar
+// registers: about twenty VALU/SALU instructions and no trip through the LDS
+// crossbar, which a butterfly of six __shfl_xor pays six times over (and the chain
+// below runs one of these per step).
+__device__ __forceinline__ unsigned int wave_or32(unsigned int v) {
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    return __builtin_amdgcn_readlane(v, 15) | __builtin_amdgcn_readlane(v, 31) |
+           __builtin_amdgcn_readlane(v, 47) | __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ unsigned long long wave_or(unsigned long long v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m, 64);
-    return v;
+    return ((unsigned long long)wave_or32((unsigned int)(v >> 32)) << 32) | wave_or32((unsigned int)v);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(REDUCE_THREADS)
 nms_reduce_kernel(int N, int C, const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                   const int* __restrict__ mask_off, const unsigned long long* __restrict__ mask,
                   size_t mask_stride, int* __restrict__ kept_pos, int* __restrict__ seg_kept) {
     __shared__ unsigned long long removed[REDUCE_MAX_WORDS];
-    __shared__ unsigned long long kbits;
+    __shared__ unsigned long long keepw[REDUCE_MAX_WORDS];
     const int c = blockIdx.x, b = blockIdx.y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int s = seg_start[b * C + c];
     const int n = seg_end[b * C + c] - s;
     if (n <= 0) {
@@ -436,43 +452,98 @@ nms_reduce_kernel(int N, int C, const int* __restrict__ seg_start, const int* __
         return;
     }
     const int T = (n + 63) >> 6;
+    if (T == 1 && wave != 0) return;                     // a one-group segment is wave 0's alone: no barrier below
     const unsigned long long* tiles = mask + (size_t)b * mask_stride + mask_off[b * C + c];
     auto tile = [&](int ti, int tj) { return tiles + (size_t)(ti * T - ti * (ti - 1) / 2 + tj - ti) * 64; };
     int* kp = kept_pos + (size_t)b * N + s;
-    for (int w = threadIdx.x; w < T; w += 256) removed[w] = 0;
-    __syncthreads();
+    if (T > 1) {
+        for (int w = threadIdx.x; w < T; w += REDUCE_THREADS) removed[w] = 0;
+        __syncthreads();
+    }
     int nk = 0;
-    unsigned long long d_next = wave == 0 ? tile(0, 0)[lane] : 0;
+    unsigned long long d = 0, nxt = 0, near = 0;
+    constexpr int H = REDUCE_THREADS / 64 - 1, U = 4;        // helper waves, tiles a helper keeps in flight
+    unsigned long long pf[U];                                // helpers: row t+1's tiles, fetched a step ahead
+    auto prefetch = [&](int t) {                             // words t+2+(wave-1), +H, ... of tile row t
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int w = t + 2 + (wave - 1) + u * H;
+            pf[u] = w < T ? tile(t, w)[lane] : 0ull;
+        }
+    };
+    if (wave == 0) {
+        d = tile(0, 0)[lane];
+        if (T > 1) nxt = tile(0, 1)[lane];
+    } else if (T > 2) {
+        prefetch(0);
+    }
     for (int g = 0; g < T; ++g) {
         if (wave == 0) {
-            const unsigned long long d = d_next;
-            if (g + 1 < T) d_next = tile(g + 1, g + 1)[lane];         // prefetch the next diagonal tile
+            unsigned long long d_next = 0, nxt_next = 0;                // the next step's two tiles, a step ahead
+            if (g + 1 < T) d_next = tile(g + 1, g + 1)[lane];
+            if (g + 2 < T) nxt_next = tile(g + 1, g + 2)[lane];
             const int left = n - g * 64;
             const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-            unsigned long long rem = removed[g] | ~valid;
+            unsigned long long rem = (T > 1 ? removed[g] : 0ull) | near | ~valid;
             unsigned long long act = __ballot(d != 0ull) & ~rem;
             while (act) {
+                // the first box still standing survives; what it suppresses leaves the
+                // list at once, so the loop takes one step per SURVIVOR with a non-empty
+                // row, not one per box
                 const int i = __ffsll((long long)act) - 1;
-                act &= act - 1ull;
-                if (!((rem >> i) & 1ull)) {
-                    const unsigned int dlo = __builtin_amdgcn_readlane((unsigned int)d, i);
-                    const unsigned int dhi = __builtin_amdgcn_readlane((unsigned int)(d >> 32), i);
-                    rem |= ((unsigned long long)dhi << 32) | dlo;
-                }
+                const unsigned int dlo = __builtin_amdgcn_readlane((unsigned int)d, i);
+                const unsigned int dhi = __builtin_amdgcn_readlane((unsigned int)(d >> 32), i);
+                rem |= ((unsigned long long)dhi << 32) | dlo;
+                act &= ~rem & ~(1ull << i);
             }
             const unsigned long long keep = ~rem;
             if ((keep >> lane) & 1ull) kp[nk + __popcll(keep & ((1ull << lane) - 1ull))] = g * 64 + lane;
-            if (lane == 0) kbits = keep;
+            nk += __popcll(keep);
+            if (g + 1 < T) {
+                if (lane == 0) keepw[g] = keep;
+                near = wave_or(((keep >> lane) & 1ull) ? nxt : 0ull);
+            }
+            d = d_next;
+            nxt = nxt_next;
+        } else if (g >= 1) {
+            const int t = g - 1;                                         // published before the last barrier
+            const bool mine = (keepw[t] >> lane) & 1ull;
+            // the first H*U words behind the chain's own come from the registers filled a step ago
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int w = t + 2 + (wave - 1) + u * H;
+                if (w < T) {                                             // wave-uniform
+                    const unsigned long long r = wave_or(mine ? pf[u] : 0ull);
+                    if (lane == 0 && r) removed[w] |= r;
+                }
+            }
+            // segments of more than (H*U + 2) * 64 boxes: the words further out are fetched here
+            for (int w0 = t + 2 + (wave - 1) + H * U; w0 < T; w0 += H * U) {
+                unsigned long long v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int w = w0 + u * H;
+                    v[u] = (w < T && mine) ? tile(t, w)[lane] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int w = w0 + u * H;
+                    if (w < T) {
+                        const unsigned long long r = wave_or(v[u]);
+                        if (lane == 0 && r) removed[w] |= r;
+                    }
+                }
+            }
+            if (g + 2 < T) prefetch(g);                                  // row t+1, consumed at the next step
         }
-        __syncthreads();
-        const unsigned long long keep = kbits;
-        const bool mine = (keep >> lane) & 1ull;
-        for (int w = g + 1 + wave; w < T; w += 4) {
-            const unsigned long long v = wave_or(mine ? tile(g, w)[lane] : 0ull);
-            if (lane == 0 && v) removed[w] |= v;
+        if (T > 1) {
+            // LDS traffic only crosses this barrier: a bare s_barrier behind an LDS wait.
+            // (__syncthreads() would also wait for wave 0's tile loads of the next step,
+            // putting a global-memory round trip back into every step of the chain.)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
-        nk += __popcll(keep);
-        __syncthreads();
     }
     if (threadIdx.x == 0) seg_kept[b * C + c] = nk;
 }
@@ -679,7 +750,7 @@ static int run_filter_results(const float* pred, int B, int N, int D, int C, flo
     hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, B), dim3(256), 0, stream, w.keys, w.key_stride,
                        N, C, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles, w.boxes, 1,
                        nms_thresh, w.mask, w.mask_stride);
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(C, B), dim3(256), 0, stream, N, C, w.seg_start, w.seg_end,
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(C, B), dim3(REDUCE_THREADS), 0, stream, N, C, w.seg_start, w.seg_end,
                        w.mask_off, w.mask, w.mask_stride, w.kept_pos, w.seg_kept);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, B * C, w.seg_off,
                        out_count);
@@ -769,7 +840,7 @@ extern "C" int yolo_amd_filter_img_class(const float* rows8, int m, float cls, f
     hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, 1), dim3(256), 0, stream, w.keys, w.key_stride,
                        m, 1, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles,
                        reinterpret_cast<const float4*>(rows8), 2, nms_thresh, w.mask, w.mask_stride);
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1, 1), dim3(256), 0, stream, m, 1, w.seg_start, w.seg_end,
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(1, 1), dim3(REDUCE_THREADS), 0, stream, m, 1, w.seg_start, w.seg_end,
                        w.mask_off, w.mask, w.mask_stride, w.kept_pos, w.seg_kept);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, 1, w.seg_off,
                        out_count);
