@@ -606,11 +606,14 @@ conv_igemm_kernel(const ConvArgs a) {
 // 48 KiB of LDS and <= 168 registers: three workgroups per CU (four waves); the
 // eight-wave form takes 76 KiB, two workgroups per CU (see the LDS map in the kernel).
 // 13 divides every feature-map side of a 416-pixel input (13 * 2^n).
-constexpr int P3_TS = 13;                  // spatial tile side
-constexpr int P3_NPIX = P3_TS * P3_TS;     // 169 output pixels per tile
-constexpr int P3_TP = 11;                  // pixel groups of 16 (176 slots)
-constexpr int P3_PLANE = 256 * 16;         // bytes per patch plane (16 rows x 16 slots x 16 B)
-constexpr int P3_PATCH = 4 * P3_PLANE;     // 16 KiB per buffer
+//
+// The tile is TH rows x TW columns of output pixels (TW + 2 <= 16: a patch row fits the 16
+// slots of a plane row).  13 x 13 serves the 13 * 2^n maps of a 416-pixel input; 19 x 10
+// serves the 19 * 2^n maps of a 608-pixel input (190 pixels = twelve groups of 16 less two
+// slots, six groups per wave pair half; the maps' widths are not multiples of 10, so the last
+// tile of a row hangs over the edge: its patch reads beyond the map come from the zero page
+// like any padding, its outputs beyond the map are not stored -- 19 of 20 columns are real).
+constexpr int P3_TS = 13;                  // spatial tile side of the default shape
 
 struct Conv3Args {
     const __bf16* src;
@@ -638,7 +641,7 @@ struct Conv3Args {
 // TC = channel groups of 16 per wave: 2 (workgroup = 128 channels) or 4 (256 channels: a wave
 // then issues 24 MFMAs per tap for 6 + 4 fragment reads instead of 12 for 6 + 2; the weight
 // ring grows to 96 KiB, one workgroup of eight waves per CU, up to 256 registers).
-template <int WAVES, int STG = 1, int TC = 2>
+template <int WAVES, int STG = 1, int TC = 2, int TH = P3_TS, int TW = P3_TS>
 __global__ void __launch_bounds__(64 * WAVES)
     __attribute__((amdgpu_waves_per_eu(TC == 4 ? 2 : (WAVES == 4 ? 3 : 4), TC == 4 ? 2 : (WAVES == 4 ? 3 : 4))))
 conv3x3_patch_kernel(const Conv3Args a) {
@@ -646,17 +649,25 @@ conv3x3_patch_kernel(const Conv3Args a) {
     static_assert(TC == 2 || (TC == 4 && WAVES == 8 && STG == 3), "the 256-channel tile exists for eight waves, row-deep stages");
     constexpr int CT = 64 * TC;                    // channels per workgroup
     constexpr int WSTAGE = CT * 64;                // bytes of one (chunk, tap) weight stage: CT channels x 32 bf16
+    static_assert(TW + 2 <= 16, "a patch row must fit the 16 slots of a plane row");
+    constexpr int P3_NPIX = TH * TW;               // output pixels per tile
+    constexpr int P3_TP = (P3_NPIX + 15) / 16;     // pixel groups of 16
+    constexpr int PROWS = (TH + 2 + 3) / 4 * 4;    // patch rows, in whole LDS-DMA instructions of four rows
+    constexpr int P3_PLANE = PROWS * 256;          // bytes per patch plane (rows x 16 slots x 16 B)
+    constexpr int P3_PATCH = 4 * P3_PLANE;         // one buffer: four 16-byte chunks of the 32 channels
     constexpr int NH = WAVES / 4;                  // waves per channel group
-    constexpr int NTP = NH == 1 ? P3_TP : 6;       // pixel groups per wave (upper bound)
-    constexpr int PP = 16 / WAVES;                 // patch LDS-DMA instructions per wave per chunk
+    constexpr int NTP = NH == 1 ? P3_TP : (P3_TP + 1) / 2;   // pixel groups per wave (upper bound)
+    constexpr int PP = (PROWS / 4) / NH;           // patch LDS-DMA instructions per wave per chunk
+    static_assert((PROWS / 4) % NH == 0 && PP <= 4 && (NH == 2 ? NTP <= 6 : P3_TP == 11),
+                  "tile shape not laid out for this wave count");
     constexpr int WP = (CT / 16) / WAVES;          // weight LDS-DMA instructions per wave per stage
     // LDS: weight ring, then the two patch buffers X and Y.  The eight-wave form adds
     // 28 KiB behind Y: Y + that is where the residual tile (176 rows x 256 B = 44 KiB)
     // is parked by LDS-DMA during the LAST chunk, which is made to read buffer X
     // (chunks alternate X/Y counted from the end), so that the residual round trip to
     // memory runs under the matrix work instead of after it.
-    constexpr bool RPRE = WAVES == 8 && STG == 1;
-    constexpr int TILE_BYTES = 176 * CT * 2;
+    constexpr bool RPRE = WAVES == 8 && STG == 1 && TH == 13 && TW == 13;
+    constexpr int TILE_BYTES = P3_TP * 16 * CT * 2;
     constexpr int RING_BYTES = 2 * STG * WSTAGE;            // two stages of STG taps
     __shared__ __attribute__((aligned(1024))) char lds_all[RING_BYTES + 2 * P3_PATCH + (RPRE ? TILE_BYTES - P3_PATCH : 0)];
     static_assert(sizeof(lds_all) >= TILE_BYTES, "the epilogue tile reuses this memory");
@@ -674,8 +685,8 @@ conv3x3_patch_kernel(const Conv3Args a) {
         a.trace[(size_t)blockIdx.x * 8 + 4] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                               (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     const int cg = w & 3, half = w >> 2;           // channel group (= patch plane), pixel-group half
-    const int tp0 = half * 6;                      // first pixel group of this wave
-    const int ntp = NH == 1 ? P3_TP : (half == 0 ? 6 : P3_TP - 6);
+    const int tp0 = half * NTP;                    // first pixel group of this wave
+    const int ntp = NH == 1 ? P3_TP : (half == 0 ? NTP : P3_TP - NTP);
 
     int tile;
     {
@@ -688,15 +699,15 @@ conv3x3_patch_kernel(const Conv3Args a) {
     const int n0 = tile_n * CT;
     const int per_img = a.tiles_y * a.tiles_x;
     const int cb = gt / per_img;
-    const int oy0 = ((gt - cb * per_img) / a.tiles_x) * P3_TS;
-    const int ox0 = ((gt - cb * per_img) % a.tiles_x) * P3_TS;
+    const int oy0 = ((gt - cb * per_img) / a.tiles_x) * TH;
+    const int ox0 = ((gt - cb * per_img) % a.tiles_x) * TW;
 
     const int r = lane & 15, q = lane >> 4;
     int tyb[NTP];                              // byte offset of (plane q, patch row ty) per pixel group
 #pragma unroll
     for (int tp = 0; tp < NTP; ++tp) {
         const int p = min((tp0 + tp) * 16 + r, P3_NPIX - 1);
-        tyb[tp] = q * P3_PLANE + (p / P3_TS) * 256;
+        tyb[tp] = q * P3_PLANE + (p / TW) * 256;
     }
     const int wfrag = (cg * 16 * TC) * 64 + slot_of<32>(r, q) * 16;
 
@@ -707,9 +718,9 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
     for (int ii = 0; ii < PP; ++ii) {
         const int py = 4 * (half * PP + ii) + q, slot = r;
-        const int px = (slot - P3_TS * py) & 15;
+        const int px = (slot - TW * py) & 15;
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-        poff[ii] = (py < P3_TS + 2 && px < P3_TS + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+        poff[ii] = (py < TH + 2 && px < TW + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
                        ? ((cb * a.H + iy) * a.W + ix) * a.C + cg * 8
                        : -1;
     }
@@ -717,6 +728,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
         // (selected with compares: a run-time index would move the array out of registers)
         int po;
         if constexpr (PP == 4) po = ii == 0 ? poff[0] : ii == 1 ? poff[1] : ii == 2 ? poff[2] : poff[3];
+        else if constexpr (PP == 3) po = ii == 0 ? poff[0] : ii == 1 ? poff[1] : poff[2];
         else po = ii == 0 ? poff[0] : poff[1];
         const __bf16* pp = po >= 0 ? a.src + (po + chunk * 32) : a.zero;
         lds_dma16(pp, lds + ((NCH - 1 - chunk) & 1) * P3_PATCH + cg * P3_PLANE + (half * PP + ii) * 1024);
@@ -774,7 +786,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 for (int kw = 0; kw < 3; ++kw) {
                     if (next_row) issue_w(nchunk, ntap0 + kw, (base ^ 3) + kw);
                     if (kh == 0 && kw < PP && more_chunks) issue_patch(chunk + 1, kw);
-                    const int colb = ((r + kw + P3_TS * kh) & 15) * 16 + kh * 256;
+                    const int colb = ((r + kw + TW * kh) & 15) * 16 + kh * 256;
                     const char* ws = wring + (base + kw) * WSTAGE + wfrag;
                     bf16x8 wf[TC], xf[6];
 #pragma unroll
@@ -784,7 +796,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     if (a.prio & 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                     for (int tp = 0; tp < 6; ++tp) {
-                        if (tp == 5 && ntp == 5) break;                 // the second half has five groups
+                        if (tp >= ntp) break;                           // the second half may have a group less
 #pragma unroll
                         for (int tc = 0; tc < TC; ++tc)
                             acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
@@ -820,7 +832,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     const int c = (lane & 15) ^ (row & 15);
                     const __bf16* src = a.zero;
                     if (row < P3_NPIX) {
-                        const int ty = row / P3_TS, tx = row - ty * P3_TS;
+                        const int ty = row / TW, tx = row - ty * TW;
                         src = a.res + (((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + n0 + c * 8;
                     }
                     lds_dma16(src, rtile + j * 1024);
@@ -828,7 +840,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 }
             }
 
-            const int colb = ((r + kw + P3_TS * kh) & 15) * 16 + kh * 256;
+            const int colb = ((r + kw + TW * kh) & 15) * 16 + kh * 256;
             const char* ws = wring + buf * WSTAGE + wfrag;
             bf16x8 wf[TC];
 #pragma unroll
@@ -840,7 +852,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 if (a.prio & 1) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) {
-                    if (NH == 2 && tp == 5 && ntp == 5) break;          // the second half has five groups
+                    if (NH == 2 && tp >= ntp) break;                    // the second half may have a group less
 #pragma unroll
                     for (int tc = 0; tc < TC; ++tc)
                         acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
@@ -868,10 +880,11 @@ conv3x3_patch_kernel(const Conv3Args a) {
     stamp(2);
     const int cq = q * 4;
     if (!a.dst_fp32 && (a.Cout & 7) == 0) {
-        constexpr int NSLOT = 176;
+        constexpr int NSLOT = P3_TP * 16;
         auto pix = [&](int slot) -> long long {
             if (slot >= P3_NPIX) return -1;
-            const int ty = slot / P3_TS, tx = slot - ty * P3_TS;
+            const int ty = slot / TW, tx = slot - ty * TW;
+            if (oy0 + ty >= a.H || ox0 + tx >= a.W) return -1;         // a tile that hangs over the edge
             return ((long long)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
         };
         wait_vmcnt<0>();
@@ -907,7 +920,8 @@ conv3x3_patch_kernel(const Conv3Args a) {
     for (int tp = 0; tp < NTP; ++tp) {
         const int p = (tp0 + tp) * 16 + r;
         if (tp >= ntp || p >= P3_NPIX) continue;
-        const int ty = p / P3_TS, tx = p - ty * P3_TS;
+        const int ty = p / TW, tx = p - ty * TW;
+        if (oy0 + ty >= a.H || ox0 + tx >= a.W) continue;
         const size_t m = ((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc) {
@@ -1639,6 +1653,7 @@ struct ConvChoice {
     int amul = 1, nstage = 0;       // im2col kernel: activation tile depth in K steps, LDS ring depth
     int waves = 4;                  // waves per workgroup
     int stg = 0;                    // patch kernel: taps per weight stage
+    int th = 0, tw = 0;             // patch kernel: output tile, rows x columns
     int ksteps = 0, kslices = 1;    // split reduction: K-steps (of 32) per slice, slices
     int Ho = 0, Wo = 0;
     long long M = 0;
@@ -1717,13 +1732,25 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
     // (YOLO_AMD_CONV3_MIN moves the threshold).  With tap-deep stages (YOLO_AMD_CONV3_STG=1) the four-wave
     // form takes the layers with more than six tiles per CU.  YOLO_AMD_CONV3=0/1 and
     // YOLO_AMD_CONV3_WAVES=4/8 force the choice (development knobs).
-    const long long p3_groups = (long long)d.B * (d.H / P3_TS) * (d.W / P3_TS) * (d.cout_pad / 128);
+    // Tile shapes: 13 x 13 on 13 * 2^n maps (416-pixel inputs), 19 x 10 on 19 * 2^n maps (608).
+    int th = 0, tw = 0;
+    if (d.H % 13 == 0 && d.W % 13 == 0) { th = 13; tw = 13; }
+    else if (d.H % 19 == 0 && d.W % 19 == 0) { th = 19; tw = 10; }
+    const long long p3_groups = th ? (long long)d.B * ((d.H + th - 1) / th) * ((d.W + tw - 1) / tw) * (d.cout_pad / 128) : 0;
     const int p3 = env_int("YOLO_AMD_CONV3", -1);
-    if (d.ksize == 3 && d.stride == 1 && d.c1 == 0 && d.up0 == 0 && d.H % P3_TS == 0 && d.W % P3_TS == 0 &&
+    if (d.ksize == 3 && d.stride == 1 && d.c1 == 0 && d.up0 == 0 && th != 0 &&
         d.cout_pad % 128 == 0 && !d.decode &&
         (p3 == 1 || (p3 < 0 && p3_groups >= env_int("YOLO_AMD_CONV3_MIN", 128)))) {
         c.kernel = YOLO_AMD_KERNEL_PATCH;
-        c.bm = P3_NPIX; c.bn = 128; c.bk = 32;
+        c.th = th; c.tw = tw;
+        c.bm = th * tw; c.bn = 128; c.bk = 32;
+        if (th != 13) {
+            // the 21-row patch buffers leave room for a tap-deep weight ring only
+            // (64 KiB, two workgroups per CU)
+            c.stg = 1; c.waves = 8;
+            *out = c;
+            return YA_OK;
+        }
         c.stg = env_int("YOLO_AMD_CONV3_STG", 3) == 3 ? 3 : 1;
         c.waves = env_int("YOLO_AMD_CONV3_WAVES", (c.stg == 3 || p3_groups <= 1536) ? 8 : 4) == 8 ? 8 : 4;
         if (c.waves == 4) c.stg = 1;
@@ -1808,14 +1835,17 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.src = (const __bf16*)d.src0; p.wgt = (const __bf16*)d.weight; p.bias = d.bias;
         p.res = (const __bf16*)d.residual; p.dst = d.dst; p.zero = (const __bf16*)zero_page;
         p.C = d.c0; p.H = d.H; p.W = d.W; p.Cout = d.cout; p.K = K; p.leaky = d.leaky; p.dst_fp32 = d.dst_fp32;
-        p.tiles_y = d.H / P3_TS; p.tiles_x = d.W / P3_TS; p.ntiles = d.B * p.tiles_y * p.tiles_x;
+        p.tiles_y = (d.H + c.th - 1) / c.th; p.tiles_x = (d.W + c.tw - 1) / c.tw;
+        p.ntiles = d.B * p.tiles_y * p.tiles_x;
         p.tiles_n = d.cout_pad / c.bn;
         p.prio = env_int("YOLO_AMD_CONV3_PRIO", 3);
         p.trace = nullptr;
 #ifdef YOLO_AMD_DEV_TRACE
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
 #endif
-        if (c.bn == 256)
+        if (c.th == 19)
+            hipLaunchKernelGGL((conv3x3_patch_kernel<8, 1, 2, 19, 10>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.bn == 256)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3, 4>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.waves == 8 && c.stg == 3)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
