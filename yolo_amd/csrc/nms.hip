@@ -216,6 +216,112 @@ nms_compact_kernel(const float* __restrict__ pred, int N, int D, int C, float co
     }
 }
 
+// Four lanes per row: the default form.  A wave stages 16 rows (5.4 KB at D = 85) instead of
+// 64, a block of four waves 64 rows, so six blocks = 24 waves fit a CU where the 64-row form has
+// six waves: the kernel is a chain of memory round trips per wave (tile in, counter atomic out,
+// lists out) and only waves in flight hide them.  Lane = (row, part): part p scans classes p,
+// p + 4, ... and the four partial first-index maxima are merged by two quad swaps.  The merge
+// keeps what the sequential scan returns: the first NaN if there is one, else the first
+// occurrence of the largest score.  The block's four waves reserve their list slots with ONE
+// atomic per class list (counts through LDS), as many atomics per row as the 64-row form issues.
+constexpr int COMPACT4_ROWS = 16, COMPACT4_WAVES = 4;
+
+__device__ __forceinline__ void merge_best(float& va, int& ia, float vb, int ib) {
+    const bool a_ok = ia >= 0, b_ok = ib >= 0;
+    const bool a_nan = va != va, b_nan = vb != vb;
+    const bool take_b = b_ok && (!a_ok || (b_nan && (!a_nan || ib < ia)) ||
+                                 (!a_nan && !b_nan && (vb > va || (vb == va && ib < ia))));
+    if (take_b) { va = vb; ia = ib; }
+}
+
+__global__ void __launch_bounds__(COMPACT4_WAVES * 64)
+nms_compact4_kernel(const float* __restrict__ pred, int N, int D, int C, float conf,
+                    int raw_stride, int G, int slice_bytes, int* __restrict__ cand_count,
+                    unsigned long long* __restrict__ raw_keys, float4* __restrict__ boxes,
+                    float* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int* const wcnt = reinterpret_cast<int*>(lds + COMPACT4_WAVES * slice_bytes);   // [waves][64] counts per list
+    int* const bases = wcnt + COMPACT4_WAVES * 64;                                  // [64] the block's slots per list
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    const int row0 = (blockIdx.x * COMPACT4_WAVES + wave) * COMPACT4_ROWS;
+    char* slice = lds + (size_t)wave * slice_bytes;
+    const int rows = min(COMPACT4_ROWS, N - row0);            // may be <= 0 for the tail waves
+    int mis = 0;
+    if (rows > 0) {
+        const char* src = reinterpret_cast<const char*>(pred + ((size_t)b * N + row0) * D);
+        const int nbytes = rows * D * 4;
+        mis = (int)((uintptr_t)src & 15);
+        const char* g0 = src - mis;
+        if (g0 < reinterpret_cast<const char*>(pred)) {
+            // first tile of a tensor that does not start on a 16-byte boundary
+            for (int i = lane * 4; i < nbytes; i += 256)
+                *reinterpret_cast<float*>(slice + mis + i) = *reinterpret_cast<const float*>(src + i);
+        } else {
+            const int total = mis + nbytes, full = total >> 4;
+            for (int kb = 0; kb < full; kb += 64)
+                if (kb + lane < full) lds_dma16(g0 + (size_t)(kb + lane) * 16, slice + kb * 16);
+            for (int i = (full << 4) + lane * 4; i < total; i += 256)
+                *reinterpret_cast<float*>(slice + i) = *reinterpret_cast<const float*>(g0 + i);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float* tile = reinterpret_cast<const float*>(slice + mis);
+    const int rr = lane >> 2, part = lane & 3;
+    const float* r = tile + rr * D;
+    bool pass = false;
+    float obj = 0.f;
+    if (rr < rows) {
+        obj = r[4];
+        pass = (obj > conf) && (obj > 0.0f);
+    }
+    int bi = -1;
+    float best = 0.f;
+    if (pass && part < C) {
+        // first-index maximum of this lane's classes; a NaN beats every number, the first NaN wins
+        best = r[5 + part];
+        bi = part;
+#pragma unroll 4
+        for (int j = part + 4; j < C; j += 4) {
+            const float v = r[5 + j];
+            if ((v > best) || ((v != v) && !(best != best))) { best = v; bi = j; }
+        }
+    }
+    // merge the four parts of a row (every lane of the quad ends up with the row's result)
+    merge_best(best, bi, __shfl_xor(best, 1, 64), __shfl_xor(bi, 1, 64));
+    merge_best(best, bi, __shfl_xor(best, 2, 64), __shfl_xor(bi, 2, 64));
+    const bool rep = pass && part == 0;                       // one lane speaks for the row
+    const int grp = rep ? (int)(((long long)bi * G) / C) : -1;
+    unsigned long long mymask = 0;
+    int mycount = 0;
+    for (int g = 0; g < G; ++g) {
+        const unsigned long long m = __ballot(grp == g);
+        if (grp == g) mymask = m;
+        if (lane == g) mycount = __popcll(m);
+    }
+    if (lane < G) wcnt[wave * 64 + lane] = mycount;
+    __syncthreads();
+    if (wave == 0 && lane < G) {
+        int tot = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < COMPACT4_WAVES; ++w2) tot += wcnt[w2 * 64 + lane];
+        bases[lane] = tot ? atomicAdd(&cand_count[(b * G + lane) * CNT_STRIDE], tot) : 0;
+    }
+    __syncthreads();
+    if (rep) {
+        int base = bases[grp];
+        for (int w2 = 0; w2 < wave; ++w2) base += wcnt[w2 * 64 + grp];
+        const int slot = base + __popcll(mymask & ((1ull << lane) - 1ull));
+        const int row = row0 + rr;
+        raw_keys[((size_t)b * G + grp) * raw_stride + slot] = make_key(bi, obj, row);
+        const float cx = r[0], cy = r[1], w = r[2], h = r[3];
+        const float hw = __fdiv_rn(w, 2.0f), hh = __fdiv_rn(h, 2.0f);
+        boxes[(size_t)b * N + row] = make_float4(__fsub_rn(cx, hw), __fsub_rn(cy, hh), __fadd_rn(cx, hw), __fadd_rn(cy, hh));
+        scores[(size_t)b * N + row] = best;
+    }
+}
+
 // ---------------------------------------------------------------- sort
 constexpr int SORT_THREADS = 1024;
 constexpr int SORT_LDS_KEYS = 16384;     // 128 KiB of the CU's 160 KiB LDS
@@ -731,10 +837,18 @@ static int run_filter_results(const float* pred, int B, int N, int D, int C, flo
     }
     YA_CHECK_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, stream));
 
-    // compact: LDS per wave = 64*D floats; fewer waves per block for wide rows
+    // compact: 16 rows per wave and four lanes per row where G lists fit the 64-lane
+    // bookkeeping (always: G <= 8) and the block's tiles fit 64 KiB; else 64 rows per wave,
+    // LDS per wave = 64*D floats, fewer waves per block for wide rows
     const size_t wave_lds = align_up((size_t)64 * D * sizeof(float) + 16, 16);
+    const size_t wave4_lds = align_up((size_t)COMPACT4_ROWS * D * sizeof(float) + 16, 16);
+    const size_t block4_lds = wave4_lds * COMPACT4_WAVES + (COMPACT4_WAVES + 1) * 64 * sizeof(int);
     YA_REQUIRE(wave_lds <= 150 * 1024, "filter_results: D=%d rows do not fit the LDS tile", D);
-    if (wave_lds * 2 <= 64 * 1024) {
+    if (block4_lds <= 64 * 1024 && w.G <= 64) {
+        dim3 grid((N + COMPACT4_ROWS * COMPACT4_WAVES - 1) / (COMPACT4_ROWS * COMPACT4_WAVES), B);
+        hipLaunchKernelGGL(nms_compact4_kernel, grid, dim3(COMPACT4_WAVES * 64), block4_lds, stream, pred, N, D, C,
+                           conf, w.raw_stride, w.G, (int)wave4_lds, w.cand_count, w.raw_keys, w.boxes, w.scores);
+    } else if (wave_lds * 2 <= 64 * 1024) {
         dim3 grid((N + 127) / 128, B);
         hipLaunchKernelGGL(nms_compact_kernel<2>, grid, dim3(128), wave_lds * 2, stream, pred, N, D, C,
                            conf, w.raw_stride, w.G, (int)wave_lds, w.cand_count, w.raw_keys, w.boxes, w.scores);
