@@ -630,7 +630,6 @@ struct Conv3Args {
                                        // (then YOLO_AMD_CONV3_TRACE=<device address>): per workgroup eight words:
                                        // 100 MHz timestamps (start, K loop entered, K loop done, stores issued), XCC_ID << 32 | HW_ID
     int prio;                          // raise the wave priority over the MFMA groups (about 1 %; YOLO_AMD_CONV3_PRIO=0 turns it off)
-    int res_pf_row;                    // kernel row of the last chunk in which the residual lines are touched
 };
 
 // WAVES = 4: wave cg owns all 11 pixel groups (three workgroups per CU).
@@ -783,26 +782,6 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 asm volatile("" ::: "memory");
                 const bool next_row = kh < 2 || more_chunks;
                 const int nchunk = kh < 2 ? chunk : chunk + 1, ntap0 = kh < 2 ? (kh + 1) * 3 : 0;
-                if (!more_chunks && kh == a.res_pf_row && a.res && (a.prio & 4) && n0 + CT <= a.Cout) {
-                    // Last chunk: touch the residual tile's lines so that they sit in this XCD's L2
-                    // when the epilogue's LDS-DMA asks for them (every workgroup of a one-round
-                    // launch reaches its epilogue at the same time, and 22 MB of residual then
-                    // queue on memory at once).  One 4-byte LDS-DMA per line and thread, into the
-                    // patch planes' last row, which no tap reads (a load into a register would
-                    // land after the compiler has given the register to something else).
-                    static_assert(PROWS > TH + 2, "the patch planes need a spare row for this");
-                    const int row = (int)threadIdx.x >> 1;
-                    const __bf16* pl = a.zero;
-                    if (row < P3_NPIX) {
-                        const int ty = row / TW, tx = row - ty * TW;
-                        if (oy0 + ty < a.H && ox0 + tx < a.W)
-                            pl = a.res + (((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + n0 +
-                                 (threadIdx.x & 1) * (CT / 2);
-                    }
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pl,
-                                                     (__attribute__((address_space(3))) void*)(lds + half * P3_PATCH +
-                                                         cg * P3_PLANE + (PROWS - 1) * 256), 4, 0, 0);
-                }
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
                     if (next_row) issue_w(nchunk, ntap0 + kw, (base ^ 3) + kw);
@@ -1860,7 +1839,6 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.ntiles = d.B * p.tiles_y * p.tiles_x;
         p.tiles_n = d.cout_pad / c.bn;
         p.prio = env_int("YOLO_AMD_CONV3_PRIO", 3);
-        p.res_pf_row = env_int("YOLO_AMD_CONV3_RESPF", 0);
         p.trace = nullptr;
 #ifdef YOLO_AMD_DEV_TRACE
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
