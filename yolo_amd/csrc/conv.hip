@@ -960,10 +960,21 @@ conv3x3_patch_kernel(const Conv3Args a) {
 constexpr uint32_t kRawBufferFlags = 0x00020000u;   // untyped 32-bit raw buffer descriptor word 3
 constexpr int FIRST_TH = 8, FIRST_TW = 32, FIRST_PH = FIRST_TH + 2, FIRST_PW = FIRST_TW + 2;
 
-// max(v, slope*v) for 0 < slope <= 1 as one median-of-three (no NaN
-// canonicalisation in front of it, unlike fmaxf)
+// max(v, slope*v) for 0 < slope <= 1: one multiply and one bare v_max_f32 (fmaxf / fmed3
+// put a canonicalising v_max(v, v) in front of it)
 __device__ __forceinline__ float leaky_max(float v, float slope) {
-    return __builtin_amdgcn_fmed3f(v, slope * v, __builtin_inff());
+    float r;
+    const float sv = slope * v;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+    return r;
+}
+
+// two fp32 -> one dword of two bf16 (one v_cvt_pk_bf16_f32; converting element by element
+// costs a conversion and a v_perm per value)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
 template <int COUT>
@@ -1098,21 +1109,21 @@ conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
             const uint32_t pixel = (uint32_t)((b * H + y) * W + x);
             const bool ok = y < H && x < W;
             if constexpr (NM == 2) {
-                bf16x8 pk;
+                u32x4 w;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) pk[4 * i + t] = (__bf16)leaky_max(acc[i][t], slope);
-                u32x4 w = __builtin_bit_cast(u32x4, pk);
+                    for (int t = 0; t < 2; ++t)
+                        w[2 * i + t] = pack_bf16x2(leaky_max(acc[i][2 * t], slope), leaky_max(acc[i][2 * t + 1], slope));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) w[t] = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)w[t]);
                 const uint32_t o = ok ? pixel * (uint32_t)(COUT * 2) + 16u * (lane & 3) : 0xFFFFFFF0u;
                 __builtin_amdgcn_raw_buffer_store_b128(w, rd, (int)o, 0, 0);
             } else {
-                bf16x4 pk;
+                u32x2 w;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) pk[t] = (__bf16)leaky_max(acc[0][t], slope);
-                u32x2 w = __builtin_bit_cast(u32x2, pk);
+                for (int t = 0; t < 2; ++t)
+                    w[t] = pack_bf16x2(leaky_max(acc[0][2 * t], slope), leaky_max(acc[0][2 * t + 1], slope));
 #pragma unroll
                 for (int t = 0; t < 2; ++t) w[t] = (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)w[t]);
                 const uint32_t o = ok ? pixel * (uint32_t)(COUT * 2) + 8u * (lane & 3) : 0xFFFFFFF0u;
@@ -1279,14 +1290,17 @@ conv_stem_kernel(const StemArgs a) {
             }
             const int y = 2 * oy0 - 1 + pr, x = 2 * ox0 - 1 + pc;
             const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            bf16x8 pk;
+            u32x4 pk;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    pk[4 * m + t] = inside ? (__bf16)leaky_max(acc0[m][t], a.slope0) : (__bf16)0.f;
+                for (int t = 0; t < 2; ++t) {
+                    const uint32_t two = pack_bf16x2(leaky_max(acc0[m][2 * t], a.slope0),
+                                                     leaky_max(acc0[m][2 * t + 1], a.slope0));
+                    pk[2 * m + t] = inside ? two : 0u;
+                }
             if (p < STEM_NPIX)
-                *reinterpret_cast<bf16x8*>(l0 + (((q * STEM_PR + pr) * 2 + (pc & 1)) * STEM_HALF + (pc >> 1)) * 16) = pk;
+                *reinterpret_cast<u32x4*>(l0 + (((q * STEM_PR + pr) * 2 + (pc & 1)) * STEM_HALF + (pc >> 1)) * 16) = pk;
         }
         __syncthreads();
 
