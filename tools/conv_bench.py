@@ -28,7 +28,10 @@ LAYERS = [
     ("3x3 128->256 @52", 52, 128, 256, 3, 1, True),
     ("3x3 256->512 @26", 26, 256, 512, 3, 1, True),
     ("3x3 512->1024 @13", 13, 512, 1024, 3, 1, True),
+    ("3x3s2 64->128 @208", 208, 64, 128, 3, 2, False),
+    ("3x3s2 128->256 @104", 104, 128, 256, 3, 2, False),
     ("3x3s2 256->512 @52", 52, 256, 512, 3, 2, False),
+    ("3x3s2 512->1024 @26", 26, 512, 1024, 3, 2, False),
     ("1x1  64->32  @208", 208, 64, 32, 1, 1, False),
     ("1x1 128->64  @104", 104, 128, 64, 1, 1, False),
     ("1x1 256->128 @52", 52, 256, 128, 1, 1, False),
