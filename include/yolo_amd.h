@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define YOLO_AMD_ABI_VERSION 5
+#define YOLO_AMD_ABI_VERSION 6
 #define YOLO_AMD_MAX_HEADS 4
 #define YOLO_AMD_MAX_ANCHORS 8
 
@@ -174,6 +174,35 @@ int yolo_amd_preprocess(const yolo_amd_image* images, int batch, int inp_dim, in
  * k = (kh*ksize + kw)*Cin + c (Cin a multiple of 32): the 32-wide slice of
  * reduction indices a workgroup stages for its channel tile is one contiguous
  * run of whole cache lines. */
+
+/* BatchNorm2d on BATCH statistics behind a convolution: what the modules of
+ * utilis.create_module (/root/reference/utilis.py:186-189) compute while the model is
+ * in train() mode, which is how /root/reference/video.py:21-25 and get_fps.py:25-29 run
+ * yolo_v3.forward (they never call eval()).  A layer whose descriptor points at one of
+ * these runs as four launches: the convolution with the UNFOLDED weights into `raw`
+ * (fp32, bias added, no activation), per-channel sums over all B*Ho*Wo pixels
+ * (float64, added in a fixed order: results do not vary from run to run), the
+ * statistics (biased variance; running_mean / running_var / num_batches_tracked
+ * updated in place as torch.nn.BatchNorm2d does, the running variance with the
+ * unbiased estimate), then (raw - mean) / sqrt(var + eps) * gamma + beta, LeakyReLU,
+ * the residual add and the one rounding to bf16 into the descriptor's dst.
+ * All pointers are device pointers; the three scratch buffers may be shared by the
+ * layers of one stream. */
+#define YOLO_AMD_BN_MAX_PARTIALS 256
+typedef struct {
+    float* raw;               /* scratch: >= B*Ho*Wo*cout floats                       */
+    double* partial;          /* scratch: >= YOLO_AMD_BN_MAX_PARTIALS * cout * 2 doubles */
+    float* scale_shift;       /* scratch: >= 2 * cout floats                            */
+    const float* gamma;       /* BatchNorm2d.weight [cout]                              */
+    const float* beta;        /* BatchNorm2d.bias [cout]                                */
+    float* running_mean;      /* [cout], updated in place; NULL: not tracked            */
+    float* running_var;       /* [cout], updated in place; NULL: not tracked            */
+    long long* num_batches_tracked; /* one int64, incremented; NULL: not tracked        */
+    float eps;                /* BatchNorm2d.eps                                        */
+    float momentum;           /* BatchNorm2d.momentum; < 0: cumulative moving average   */
+                              /* (momentum=None: factor 1 / num_batches_tracked)        */
+} yolo_amd_bn_train;
+
 typedef struct {
     const void* src0;     /* NHWC bf16, (B, H >> up0, W >> up0, c0); for the   */
                           /* first layer: NCHW fp32 (B, c0, H, W)               */
@@ -189,7 +218,8 @@ typedef struct {
     int k_pad;            /* reduction length K = ksize*ksize*(c0 + c1)         */
     int leaky;            /* apply LeakyReLU(0.1)                               */
     int dst_fp32;         /* 1: dst is fp32 (detection convs), 0: bf16          */
-    int first_layer;      /* 1: src0 is the NCHW fp32 network input             */
+    int first_layer;      /* 1: src0 is the NCHW fp32 network input (dst_fp32 is  */
+                          /* allowed there only without fuse_next)              */
     /* Detection convolutions can run yolo_v3.predict in their epilogue
      * (/root/reference/yolo_v3.py:205-262) instead of leaving it to
      * yolo_amd_decode: with decode != NULL (host pointer; needs dst_fp32,
@@ -211,6 +241,12 @@ typedef struct {
      * they differ in the last bits from the unsplit layer. */
     void* splitk_ws;
     size_t splitk_ws_bytes;
+    /* Host pointer or NULL.  Not NULL: `weight` holds the convolution's own weights
+     * (no BatchNorm folded), `bias` its bias (zeros without one), and the layer is
+     * normalised on batch statistics as described at yolo_amd_bn_train; needs a
+     * bf16 dst, cout a multiple of 8, more than one output pixel per channel, no
+     * decode and no fuse_next. */
+    const yolo_amd_bn_train* bn_train;
 } yolo_amd_conv_desc;
 
 /* Scratch bytes the split reduction of this layer wants (0: it would not be

@@ -115,13 +115,20 @@ def layer_table(blocks, channels, num_classes, num_anchors,
 
 
 # --------------------------------------------------------------------------
-# forward (torch CPU fp32 ops, eval-mode BatchNorm)
+# forward (torch CPU fp32 ops)
 # --------------------------------------------------------------------------
-def forward(state_dict, blocks, params, x, return_layers=False):
-    """yolo_v3.forward with is_training=False in eval() mode
-    (yolo_v3.py:449-496).  ``state_dict`` uses the reference's key names
-    (module_list.<i>.conv_<i>.weight, module_list.<i>.bach_norm_<i>.*).
-    ``x`` is a (B, C, H, H) float32 torch tensor on the CPU.
+def forward(state_dict, blocks, params, x, return_layers=False, training=False):
+    """yolo_v3.forward with is_training=False (yolo_v3.py:449-496).  ``state_dict``
+    uses the reference's key names (module_list.<i>.conv_<i>.weight,
+    module_list.<i>.bach_norm_<i>.*).  ``x`` is a (B, C, H, H) float32 torch tensor
+    on the CPU.
+
+    training=False is the model after eval(): BatchNorm2d on its running statistics.
+    training=True is the model as constructed (video.py:21-25 and get_fps.py:25-29
+    never call eval()): every BatchNorm2d normalises with the batch's own mean and
+    biased variance and moves running_mean / running_var (momentum 0.1, unbiased
+    variance) and num_batches_tracked; the moved statistics are written back into
+    ``state_dict`` (new tensors: the caller's originals are not modified in place).
     """
     import torch
     import torch.nn.functional as F
@@ -141,11 +148,20 @@ def forward(state_dict, blocks, params, x, return_layers=False):
                 x = F.conv2d(x, w, b, stride=ent["stride"], padding=ent["pad"])
                 if ent["bn"]:
                     p = f"module_list.{i}.bach_norm_{i}."
-                    x = F.batch_norm(x, state_dict[p + "running_mean"],
-                                     state_dict[p + "running_var"],
-                                     state_dict[p + "weight"],
-                                     state_dict[p + "bias"],
-                                     training=False, momentum=0.1, eps=1e-5)
+                    if training:
+                        rm = state_dict[p + "running_mean"].clone()
+                        rv = state_dict[p + "running_var"].clone()
+                        x = F.batch_norm(x, rm, rv, state_dict[p + "weight"], state_dict[p + "bias"],
+                                         training=True, momentum=0.1, eps=1e-5)
+                        state_dict[p + "running_mean"], state_dict[p + "running_var"] = rm, rv
+                        key = p + "num_batches_tracked"
+                        state_dict[key] = state_dict.get(key, torch.zeros((), dtype=torch.int64)) + 1
+                    else:
+                        x = F.batch_norm(x, state_dict[p + "running_mean"],
+                                         state_dict[p + "running_var"],
+                                         state_dict[p + "weight"],
+                                         state_dict[p + "bias"],
+                                         training=False, momentum=0.1, eps=1e-5)
                 if ent["leaky"]:
                     x = F.leaky_relu(x, 0.1)
             elif t == "upsample":

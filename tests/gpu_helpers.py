@@ -63,7 +63,7 @@ def oracle_forward(sd, H, C, A, x_np, return_layers=False):
 
 
 def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None, fp32_out=False,
-             splitk=False, info=None):
+             splitk=False, info=None, bn=None):
     """One fused layer through yolo_amd_conv_forward.  splitk: lend the scratch the
     library asks for, so a layer with few output tiles splits its reduction; info (a
     dict) receives "splitk_bytes" and "choice" (the kernel the library picks, as
@@ -71,6 +71,9 @@ def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None
 
     x0: (B, H0, W0, c0) bf16 NHWC cuda; x1: optional (B, H, W, c1) bf16;
     w: (cout, cin, k, k) fp32 (already BN-folded); bias: (cout,) fp32.
+    bn: dict(gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum) of
+    CUDA tensors / floats: BatchNorm2d on batch statistics behind the convolution (w then
+    holds the convolution's own weights); the running tensors are updated in place.
     Returns the NHWC output tensor (bf16, or fp32 when fp32_out)."""
     from yolo_amd import _lib
     from yolo_amd._lib import ConvDesc, lib, check
@@ -108,6 +111,18 @@ def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None
     if splitk and need:
         ws = torch.full((need,), 0xFF, dtype=torch.uint8, device=dev)      # NaN-filled scratch
         d[0].splitk_ws, d[0].splitk_ws_bytes = ws.data_ptr(), need
+    if bn is not None:
+        b = _lib.BnTrain()
+        keep = [torch.full((B * Ho * Wo * cout,), float("nan"), dtype=torch.float32, device=dev),
+                torch.full((_lib.BN_MAX_PARTIALS * cout * 2,), float("nan"), dtype=torch.float64, device=dev),
+                torch.full((2 * cout,), float("nan"), dtype=torch.float32, device=dev)]
+        b.raw, b.partial, b.scale_shift = (t.data_ptr() for t in keep)
+        b.gamma, b.beta = bn["gamma"].data_ptr(), bn["beta"].data_ptr()
+        for key in ("running_mean", "running_var", "num_batches_tracked"):
+            setattr(b, key, bn[key].data_ptr() if bn.get(key) is not None else None)
+        b.eps = bn.get("eps", 1e-5)
+        b.momentum = -1.0 if bn.get("momentum", 0.1) is None else bn.get("momentum", 0.1)
+        d[0].bn_train = ctypes.pointer(b)
     if info is not None:
         info["choice"] = _lib.conv_choice(d[0])      # which kernel the library runs for this layer
     check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), _lib.current_stream_ptr(dev)), "conv")

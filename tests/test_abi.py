@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} is declared in yolo_amd.h but not exported"
         assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype in yolo_amd/_lib.py"
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.yolo_amd_abi_version() == 5
+    assert _lib.lib.yolo_amd_abi_version() == 6
 
 
 def test_struct_layouts_match_the_header():
@@ -37,10 +37,12 @@ def test_struct_layouts_match_the_header():
 #include <stddef.h>
 #include "yolo_amd.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(yolo_amd_head_desc), offsetof(yolo_amd_head_desc, stride),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(yolo_amd_head_desc), offsetof(yolo_amd_head_desc, stride),
          offsetof(yolo_amd_head_desc, anchor_h), sizeof(yolo_amd_conv_desc),
          offsetof(yolo_amd_conv_desc, c0), offsetof(yolo_amd_conv_desc, first_layer),
-         offsetof(yolo_amd_conv_desc, decode), offsetof(yolo_amd_conv_desc, fuse_next));
+         offsetof(yolo_amd_conv_desc, decode), offsetof(yolo_amd_conv_desc, fuse_next),
+         offsetof(yolo_amd_conv_desc, bn_train), sizeof(yolo_amd_bn_train),
+         offsetof(yolo_amd_bn_train, num_batches_tracked), offsetof(yolo_amd_bn_train, momentum));
   return 0;
 }'''
     with tempfile.TemporaryDirectory() as tmp:
@@ -49,9 +51,11 @@ int main(void) {
         exe = os.path.join(tmp, "t")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         got = [int(v) for v in subprocess.check_output([exe]).split()]
-    H, C = _lib.HeadDesc, _lib.ConvDesc
+    H, C, N = _lib.HeadDesc, _lib.ConvDesc, _lib.BnTrain
     want = [ctypes.sizeof(H), H.stride.offset, H.anchor_h.offset, ctypes.sizeof(C), C.c0.offset,
-            C.first_layer.offset, C.decode.offset, C.fuse_next.offset]
+            C.first_layer.offset, C.decode.offset, C.fuse_next.offset, C.bn_train.offset, ctypes.sizeof(N),
+            N.num_batches_tracked.offset, N.momentum.offset]
+    assert _lib.BN_MAX_PARTIALS == int(re.search(r"#define YOLO_AMD_BN_MAX_PARTIALS\s+(\d+)", open(HEADER).read()).group(1))
     assert got == want
 
 

@@ -559,17 +559,3 @@ def test_split_heads_decode_like_the_single_pass():
     # (2^-8 relative each) here and there, and those differences travel on
     rel = ((split - single).abs() / (single.abs() + 1e-3)).flatten()
     assert rel.median() < 1e-2 and (split[..., 4] - single[..., 4]).abs().max() < 0.05
-
-
-def test_train_mode_falls_back_to_modules_with_a_warning():
-    from gpu_helpers import build_model
-    model, params, _ = build_model(64)
-    x = torch.from_numpy(gi.images(12, 2, 64)).cuda()
-    model.train()
-    with pytest.warns(UserWarning, match="train"):
-        with torch.no_grad():
-            y = model(x)
-    assert y.shape == (2, 252, 85)
-    model.eval()
-    with pytest.raises(NotImplementedError):
-        model(x, is_training=True)

@@ -146,3 +146,42 @@ def test_forward_oracle_matches_reference(case):
     got = orc.filter_results(ARR[case["name"]] if case["name"] in ARR else det, 0.5, 0.4, C)
     if case["name"] in ARR:
         assert_bit_equal(got, ARR[case["name"] + "_e2e"], "e2e rows")
+
+
+# ---- train() mode: BatchNorm2d on batch statistics (video.py / get_fps.py never call eval())
+import json as _json
+import os as _os
+
+_TRAIN_DIR = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden")
+TRAIN_META = _json.load(open(_os.path.join(_TRAIN_DIR, "golden_train.json")))
+TRAIN_ARR = np.load(_os.path.join(_TRAIN_DIR, "golden_train.npz"))
+
+
+@pytest.mark.parametrize("case", TRAIN_META["cases"], ids=lambda c: c["name"])
+def test_train_mode_forward_oracle_matches_reference(case):
+    """Two calls in train() mode (outputs, moved running statistics), then the eval()
+    model on the moved statistics, against what the reference returned
+    (tests/golden/make_golden_train.py)."""
+    H, B, C, A = case["H"], case["B"], case["C"], case["A"]
+    blocks = orc.parse_cfg_text(yolov3_cfg_text(C, A))
+    p = default_params(H, C, A)
+    table = orc.layer_table(blocks, 3, C, A)
+    sd = {k: torch.from_numpy(np.asarray(v))
+          for k, v in gi.synthetic_state_dict(table, TRAIN_META["weight_seed"]).items()}
+    before = {k: v.clone() for k, v in sd.items()}
+    for k, seed in enumerate(TRAIN_META["image_seeds"]):
+        det = orc.forward(sd, blocks, p, torch.from_numpy(gi.images(seed, B, H)), training=True).numpy()
+        np.testing.assert_allclose(det, TRAIN_ARR[f"{case['name']}_call{k}"], rtol=2e-4, atol=2e-4)
+    n_checked = 0
+    for key, dg in case["bn"].items():
+        a = sd[key].double().numpy().reshape(-1)
+        assert not np.array_equal(a, before[key].double().numpy().reshape(-1)), f"{key} did not move"
+        np.testing.assert_allclose(np.abs(a).sum(), dg["abssum"], rtol=1e-5)
+        idx = np.linspace(0, a.size - 1, min(4, a.size)).astype(np.int64)
+        np.testing.assert_allclose(a[idx], dg["samples"], rtol=1e-4, atol=1e-6)
+        n_checked += 1
+    assert n_checked == 2 * 72
+    nbt = [int(v) for k, v in sd.items() if k.endswith("num_batches_tracked")]
+    assert nbt and all(n == case["num_batches_tracked"] for n in nbt)
+    det = orc.forward(sd, blocks, p, torch.from_numpy(gi.images(TRAIN_META["image_seeds"][0], B, H))).numpy()
+    np.testing.assert_allclose(det, TRAIN_ARR[f"{case['name']}_eval_after"], rtol=2e-4, atol=2e-4)

@@ -38,6 +38,25 @@ class ImageDesc(ctypes.Structure):
                 ("pitch_bytes", ctypes.c_int64)]
 
 
+class BnTrain(ctypes.Structure):
+    """yolo_amd_bn_train: BatchNorm2d on batch statistics behind a convolution."""
+    _fields_ = [
+        ("raw", ctypes.c_void_p),
+        ("partial", ctypes.c_void_p),
+        ("scale_shift", ctypes.c_void_p),
+        ("gamma", ctypes.c_void_p),
+        ("beta", ctypes.c_void_p),
+        ("running_mean", ctypes.c_void_p),
+        ("running_var", ctypes.c_void_p),
+        ("num_batches_tracked", ctypes.c_void_p),
+        ("eps", ctypes.c_float),
+        ("momentum", ctypes.c_float),
+    ]
+
+
+BN_MAX_PARTIALS = 256
+
+
 class ConvDesc(ctypes.Structure):
     _fields_ = [
         ("src0", ctypes.c_void_p),
@@ -60,6 +79,7 @@ class ConvDesc(ctypes.Structure):
         ("fuse_next", ctypes.c_int),
         ("splitk_ws", ctypes.c_void_p),
         ("splitk_ws_bytes", ctypes.c_size_t),
+        ("bn_train", ctypes.POINTER(BnTrain)),
     ]
 
 
@@ -130,7 +150,7 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    want = 5
+    want = 6
     got = lib.yolo_amd_abi_version()
     if got != want:
         raise ImportError(f"{LIB_PATH} has ABI version {got}, the Python side expects {want}")

@@ -28,6 +28,10 @@
 
 namespace yolo_amd {
 
+// bn.hip
+int launch_bn_train(const yolo_amd_bn_train& bn, long long M, int C, const void* residual, void* dst, int leaky,
+                    hipStream_t stream);
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -977,10 +981,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
 }
 
-template <int COUT>
+// F32: the output is fp32 (32 or 64 bytes per pixel and lane quad instead of 16 or 32), for
+// layers whose BatchNorm runs on batch statistics and needs the un-normalised sums.
+template <int COUT, bool F32 = false>
 __global__ void __launch_bounds__(256)
 conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
-                  const float* __restrict__ bias, __bf16* __restrict__ dst, int B, int Cin, int H, int W,
+                  const float* __restrict__ bias, void* __restrict__ dst, int B, int Cin, int H, int W,
                   float slope, uint32_t src_bytes, uint32_t dst_bytes, int tiles_x, int tiles_y) {
     constexpr int NM = COUT / 16;
     static_assert(NM == 1 || NM == 2, "first layer: 16 or 32 output channels");
@@ -1062,9 +1068,9 @@ conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
         // carries, so the counted waits for a patch never include the stores
         // of the tiles in between.
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if constexpr (NM == 2)
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rd, (int)(0xFFFFFF00u + 16u * u), 0, 0);
+        for (int u = 0; u < (F32 ? 4 * NM : 4); ++u) {
+            if constexpr (NM == 2 || F32)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, rd, (int)(0xFFFFFF00u + 16u * (u & 3)), 0, 0);
             else
                 __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rd, (int)(0xFFFFFF00u + 16u * u), 0, 0);
         }
@@ -1108,7 +1114,20 @@ conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
             const int y = ty * FIRST_TH + row, x = tx * FIRST_TW + (sidx & 1) * 16 + (lane >> 2);
             const uint32_t pixel = (uint32_t)((b * H + y) * W + x);
             const bool ok = y < H && x < W;
-            if constexpr (NM == 2) {
+            if constexpr (F32) {
+                // 4 * NM floats per lane: chunk lane & 3 of pixel lane >> 2, as below
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    u32x4 w;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        w[t] = (uint32_t)__builtin_amdgcn_ds_bpermute(
+                            src_lane4, (int)__float_as_uint(leaky_max(acc[i][t], slope)));
+                    const uint32_t o = ok ? pixel * (uint32_t)(COUT * 4) + (uint32_t)(16 * NM) * (lane & 3) + 16u * i
+                                          : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rd, (int)o, 0, 0);
+                }
+            } else if constexpr (NM == 2) {
                 u32x4 w;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -1688,7 +1707,7 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
     YA_REQUIRE(c.M < (1ll << 31), "conv: too many output pixels");
     if (d.first_layer) {
         YA_REQUIRE(d.ksize == 3 && d.stride == 1 && d.c0 >= 1 && d.c0 <= 3 && d.c1 == 0 && !d.residual &&
-                       !d.dst_fp32 && d.up0 == 0 && !d.decode,
+                       !(d.dst_fp32 && d.fuse_next) && d.up0 == 0 && !d.decode,
                    "conv: first layer must be 3x3 stride 1 with at most 3 input channels");
         YA_REQUIRE(d.cout == 32 || d.cout == 16,
                    "conv: first layer with %d output channels is not instantiated (16 or 32)", d.cout);
@@ -1814,19 +1833,21 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
     const int Ho = c.Ho, Wo = c.Wo;
     const long long M = c.M;
     if (c.kernel == YOLO_AMD_KERNEL_FIRST) {
-        const long long src_bytes = (long long)d.B * d.c0 * d.H * d.W * 4, dst_bytes = M * d.cout * 2;
+        const long long src_bytes = (long long)d.B * d.c0 * d.H * d.W * 4, dst_bytes = M * d.cout * (d.dst_fp32 ? 4 : 2);
         YA_REQUIRE(src_bytes < (1ll << 31) && dst_bytes < 0xFFFFFF00ll,
                    "conv: first layer input must be smaller than 2 GiB and its output smaller than 4 GiB");
         const int tiles_x = (d.W + FIRST_TW - 1) / FIRST_TW, tiles_y = (d.H + FIRST_TH - 1) / FIRST_TH;
         const long long ntiles = (long long)tiles_x * tiles_y * d.B;
         dim3 grid((unsigned)std::min<long long>(ntiles, 256 * 8 * 4));
         const float slope = d.leaky ? 0.1f : 1.0f;
-#define YA_FIRST(CO)                                                                               \
-    hipLaunchKernelGGL((conv_first_kernel<CO>), grid, dim3(256), 0, stream, (const float*)d.src0, \
-                       (const float*)d.weight, d.bias, (__bf16*)d.dst, d.B, d.c0, d.H, d.W, slope, \
+#define YA_FIRST(CO, F32)                                                                               \
+    hipLaunchKernelGGL((conv_first_kernel<CO, F32>), grid, dim3(256), 0, stream, (const float*)d.src0, \
+                       (const float*)d.weight, d.bias, d.dst, d.B, d.c0, d.H, d.W, slope,              \
                        (uint32_t)src_bytes, (uint32_t)dst_bytes, tiles_x, tiles_y)
-        if (d.cout == 32) YA_FIRST(32);
-        else YA_FIRST(16);
+        if (d.cout == 32 && d.dst_fp32) YA_FIRST(32, true);
+        else if (d.cout == 32) YA_FIRST(32, false);
+        else if (d.dst_fp32) YA_FIRST(16, true);
+        else YA_FIRST(16, false);
 #undef YA_FIRST
         return YA_OK;
     }
@@ -1971,7 +1992,11 @@ extern "C" size_t yolo_amd_conv_splitk_bytes(const yolo_amd_conv_desc* d) {
 extern "C" int yolo_amd_conv_query(const yolo_amd_conv_desc* d, yolo_amd_conv_choice* out) {
     YA_REQUIRE(d && out, "conv_query: null pointer");
     ConvChoice c;
-    const int rc = choose_conv(*d, false, &c);
+    yolo_amd_conv_desc q = *d;
+    if (q.bn_train) {            // the convolution of such a layer writes the fp32 scratch
+        q.dst_fp32 = 1; q.leaky = 0; q.residual = nullptr;
+    }
+    const int rc = choose_conv(q, false, &c);
     if (rc != YA_OK) return rc;
     out->kernel = c.kernel; out->bm = c.bm; out->bn = c.bn; out->bk = c.bk;
     out->act_ksteps = c.amul; out->lds_stages = c.nstage; out->waves = c.waves;
@@ -2006,6 +2031,22 @@ static int launch_stem(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc& d
     return YA_OK;
 }
 
+// A layer whose BatchNorm runs on batch statistics: the convolution alone into the fp32
+// scratch, then the statistics and the normalising pass of bn.hip.
+static int launch_conv_bn_train(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream) {
+    YA_REQUIRE(!d.dst_fp32 && !d.decode && !d.fuse_next, "conv: a bn_train layer needs a bf16 dst, no decode, no fuse_next");
+    yolo_amd_conv_desc c = d;
+    c.bn_train = nullptr;
+    c.dst = d.bn_train->raw;
+    c.dst_fp32 = 1;
+    c.leaky = 0;
+    c.residual = nullptr;
+    YA_REQUIRE(c.dst, "conv: bn_train without a raw buffer");
+    const int rc = launch_conv(c, zero_page, stream);
+    if (rc != YA_OK) return rc;
+    return launch_bn_train(*d.bn_train, out_pixels(d), d.cout, d.residual, d.dst, d.leaky, stream);
+}
+
 extern "C" int yolo_amd_conv_forward(const yolo_amd_conv_desc* descs, int n, const void* zero_page,
                                      void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -2016,6 +2057,8 @@ extern "C" int yolo_amd_conv_forward(const yolo_amd_conv_desc* descs, int n, con
             YA_REQUIRE(i + 1 < n, "conv_forward: fuse_next on the last descriptor");
             rc = launch_stem(descs[i], descs[i + 1], stream);
             ++i;
+        } else if (descs[i].bn_train) {
+            rc = launch_conv_bn_train(descs[i], zero_page, stream);
         } else {
             rc = launch_conv(descs[i], zero_page, stream);
         }

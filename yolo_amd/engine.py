@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, HeadDesc, check, lib
+from ._lib import BnTrain, ConvDesc, HeadDesc, check, lib
 
 
 class UnsupportedGraph(NotImplementedError):
@@ -210,11 +210,20 @@ def place_buffers(buf_info):
 class Plan:
     """Descriptors and buffers for one (batch, height) shape on one device."""
 
-    def __init__(self, model, B, H, keep_all=False):
+    def __init__(self, model, B, H, keep_all=False, train=False):
         """keep_all=True gives every layer its own buffer (no reuse) so tests can
-        inspect intermediate outputs after a run."""
+        inspect intermediate outputs after a run.
+
+        train=True is the model in train() mode, which is how the callers that never
+        call eval() run it (/root/reference/video.py:21-25, get_fps.py:25-29): every
+        BatchNorm2d normalises with the statistics of the batch at hand and updates its
+        running statistics, so nothing is folded; such a layer runs as convolution ->
+        fp32 scratch -> statistics -> normalise + LeakyReLU + shortcut (csrc/bn.hip),
+        and the module's running_mean / running_var / num_batches_tracked tensors are
+        updated in place by the kernels."""
         _lib.require_gpu()
         self.keep_all = keep_all
+        self.train = bool(train)
         self.model = model
         self.B, self.H = B, H
         params = model.params
@@ -271,7 +280,8 @@ class Plan:
         # pixel then never go to memory).  Plans that keep every layer readable
         # run them separately; YOLO_AMD_STEM=0 does too (development knob).
         self.fused_stem = False
-        if (not self.keep_all and len(ops) >= 2 and os.environ.get("YOLO_AMD_STEM", "1") != "0"):
+        if (not self.keep_all and not self.train and len(ops) >= 2
+                and os.environ.get("YOLO_AMD_STEM", "1") != "0"):
             o0, o1 = ops[0], ops[1]
             e0, e1 = o0["ent"], o1["ent"]
             readers = [op for op in ops if any(s_[0] == f"L{o0['index']}" for s_ in op["src"])
@@ -292,6 +302,25 @@ class Plan:
             for j in range(len(ops)):
                 self.descs[j].splitk_ws = self._splitk.data_ptr()
                 self.descs[j].splitk_ws_bytes = need
+        # Batch-statistics BatchNorm: one fp32 scratch for the largest un-normalised
+        # convolution output, one for the partial sums, one for (scale, shift); the
+        # layers run in stream order and share them.
+        self._bn = None
+        if self.train:
+            bn_ops = [op for op in ops if op["ent"]["bn"]]
+            for op in bn_ops:
+                if op["fp32"] or op["ent"]["cout"] % 8:
+                    raise UnsupportedGraph(f"block {op['index']}: batch-statistics BatchNorm needs a bf16 output "
+                                           "with a multiple of 8 channels")
+                if B * op["Ho"] * op["Wo"] <= 1:
+                    raise ValueError("Expected more than 1 value per channel when training")
+            if bn_ops:
+                raw_elems = max(B * op["Ho"] * op["Wo"] * op["ent"]["cout"] for op in bn_ops)
+                cmax = max(op["ent"]["cout"] for op in bn_ops)
+                self._bn_raw = torch.empty(raw_elems, dtype=torch.float32, device=dev)
+                self._bn_partial = torch.empty(_lib.BN_MAX_PARTIALS * cmax * 2, dtype=torch.float64, device=dev)
+                self._bn_scale_shift = torch.empty(2 * cmax, dtype=torch.float32, device=dev)
+                self._bn = (BnTrain * len(ops))()
         self.refold()
 
         # ---- decode descriptors
@@ -349,7 +378,10 @@ class Plan:
             if cout != ent["cout"] or w.shape[1] != ent["cin"] or w.shape[2] != ent["k"]:
                 raise _lib.YoloAmdError(f"block {i}: the module holds a {tuple(w.shape)} convolution, the plan "
                                         f"was laid out for {ent['cout']}x{ent['cin']}x{ent['k']}x{ent['k']}")
-            if ent["bn"]:
+            if ent["bn"] and self.train:
+                bias = conv.bias.detach().float() if conv.bias is not None else w.new_zeros(cout)
+                self._fill_bn(j, i, seq[1])
+            elif ent["bn"]:
                 bn = seq[1]
                 scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.float() + bn.eps)
                 bias = bn.bias.detach().float() - bn.running_mean.float() * scale
@@ -369,6 +401,29 @@ class Plan:
             self._packed.append((wp, bp))
             d.weight = wp.data_ptr()
             d.bias = bp.data_ptr()
+
+    def _fill_bn(self, j, index, bn):
+        """Point layer j's batch-statistics descriptor at the module's own tensors."""
+        def ptr(t, dtype=torch.float32):
+            if t is None:
+                return None
+            if t.dtype != dtype or t.device != self.device or not t.is_contiguous():
+                raise UnsupportedGraph(f"block {index}: BatchNorm tensors must be contiguous {dtype} on {self.device}")
+            return t.data_ptr()
+        if bn.weight is None or bn.bias is None:
+            raise UnsupportedGraph(f"block {index}: BatchNorm2d without affine parameters")
+        b = self._bn[j]
+        b.raw = self._bn_raw.data_ptr()
+        b.partial = self._bn_partial.data_ptr()
+        b.scale_shift = self._bn_scale_shift.data_ptr()
+        b.gamma, b.beta = ptr(bn.weight.data), ptr(bn.bias.data)
+        track = bn.track_running_stats and bn.running_mean is not None
+        b.running_mean = ptr(bn.running_mean) if track else None
+        b.running_var = ptr(bn.running_var) if track else None
+        b.num_batches_tracked = ptr(bn.num_batches_tracked, torch.int64) if track else None
+        b.eps = float(bn.eps)
+        b.momentum = -1.0 if bn.momentum is None else float(bn.momentum)
+        self.descs[j].bn_train = ctypes.pointer(b)
 
     # ------------------------------------------------------------------ run
     def run(self, x):

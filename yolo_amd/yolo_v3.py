@@ -5,7 +5,11 @@ library instead of torch modules.
 
 ``forward(x)`` in eval() mode executes the fused plan (yolo_amd/engine.py): 75
 implicit-GEMM conv launches (bf16 MFMA, BatchNorm folded, LeakyReLU, shortcut
-add, upsample + route concat all fused) and one decode launch.  The module
+add, upsample + route concat all fused) and one decode launch.  In train() mode
+(the callers that never call eval(): /root/reference/video.py:21-25,
+get_fps.py:25-29) the same convolution kernels run with unfolded weights and every
+BatchNorm2d normalises on batch statistics in HIP kernels of its own, updating the
+modules' running statistics in place as torch does.  The module
 tree (``module_list`` with conv_<i> / bach_norm_<i> / leaky_<i>) is kept only
 so that ``state_dict()`` / ``load_state_dict()`` / ``.cuda()`` behave like the
 reference's; it is the source the plan folds its weights from.
@@ -23,7 +27,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import HeadDesc, check, lib
-from .engine import Plan
+from .engine import Plan, UnsupportedGraph
 from .utilis import create_module, box_iou, _save_checkpoint  # noqa: F401  (re-exported names)
 
 
@@ -80,6 +84,7 @@ class yolo_v3(nn.Module):
         self._plans = {}
         self._weights_version = 0
         self._device = None
+        self._running_stats_moved = False   # a train()-mode forward has updated them since the last fold
         if self.params["pretrain_snapshot"]:
             self.load_state_dict(torch.load(self.params["pretrain_snapshot"]))
         elif weight_file is not None:
@@ -113,16 +118,16 @@ class yolo_v3(nn.Module):
         edits): the fused plan folds BatchNorm into its own weight copies."""
         self._invalidate()
 
-    def _plan(self, B, H):
+    def _plan(self, B, H, train=False):
         # One plan (activation arena, split-K scratch, descriptors) per shape AND per
         # stream: calls queued on one stream run in order and share it, calls on two
         # streams may overlap on the GPU and get arenas of their own.
         dev = self._param_device()
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-        key = (B, H, stream)
+        key = (B, H, stream, train)
         plan = self._plans.get(key)
         if plan is None:
-            plan = Plan(self, B, H)
+            plan = Plan(self, B, H, train=train)
             self._plans[key] = plan
         return plan
 
@@ -131,14 +136,6 @@ class yolo_v3(nn.Module):
         if is_training:
             raise NotImplementedError("training (yolo_loss) is outside this package; use the "
                                       "reference for fit()")
-        if self.training:
-            # video.py / get_fps.py never call eval(), so the reference runs
-            # BatchNorm on batch statistics there.  A folded kernel cannot
-            # reproduce that; run the torch modules so the semantics hold.
-            warnings.warn("yolo_v3 is in train() mode: BatchNorm uses batch statistics, which "
-                          "the fused HIP path cannot fold; running the torch modules. Call "
-                          ".eval() for the fused path.", stacklevel=2)
-            return self._forward_modules(x)
         if x.dim() != 4 or x.shape[2] != x.shape[3]:
             raise ValueError("expected a (B, C, H, H) batch")
         src_device = x.device
@@ -148,6 +145,25 @@ class yolo_v3(nn.Module):
                                     "the fused path has no CPU implementation")
         if x.device != dev:
             x = x.to(dev)
+        if self.training:
+            # video.py / get_fps.py never call eval(): BatchNorm then runs on batch
+            # statistics and moves its running statistics with every call
+            try:
+                plan = self._plan(int(x.shape[0]), int(x.shape[2]), train=True)
+            except UnsupportedGraph as exc:
+                warnings.warn(f"yolo_v3 is in train() mode and the batch-statistics plan cannot take this "
+                              f"model ({exc}); running the torch modules", stacklevel=2)
+                out = self._forward_modules(x)
+                return out if src_device == dev else out.to(src_device)
+            self._running_stats_moved = True
+            out = plan.run(x)
+            return out if src_device == dev else out.to(src_device)
+        if self._running_stats_moved:
+            # the eval() plans folded running statistics that have changed since
+            for key, plan in self._plans.items():
+                if not key[3]:
+                    plan.refold()
+            self._running_stats_moved = False
         out = self._plan(int(x.shape[0]), int(x.shape[2])).run(x)
         return out if src_device == dev else out.to(src_device)
 
