@@ -214,3 +214,51 @@ def test_filter_img_class_matches_oracle():
         assert ind.shape == (want.shape[0], 1) and (ind == 3).all()
     ind, got = filter_img_class(99.0, t, 0, 0.4)
     assert got.shape == (0, 8) and ind.shape == (0, 1)
+
+
+def test_thresholds_on_the_rounding_boundary():
+    """The suppression test `iou < thresh` is decided without the division (an exact
+    float64 multiply-compare against the midpoint below thresh).  Thresholds that EQUAL
+    IoUs occurring in the data, their fp32 neighbours, powers of two, and values for which
+    the library keeps the division (zero, negative, denormal, inf, NaN); integer boxes so
+    that few distinct IoU values occur and many pairs sit exactly on the threshold; some
+    boxes with negative width or height (non-positive union)."""
+    from helpers import c_box_iou
+    C = 3
+    pred = gi.nms_pred(seed=71, B=2, N=1500, C=C, mode="clustered", tie_levels=16)
+    pred[..., :4] = np.round(pred[..., :4] / 4) * 4
+    pred[0, :60, 2] *= -3                      # negative widths: areas and unions <= 0
+    pred[1, 100:130, 3] = -1.0                 # height -1: (h + 1) = 0, zero areas
+    # IoU values between kept boxes and the other candidates of their class for which a
+    # pair sitting EXACTLY on the threshold decides a box's fate
+    out = c_filter_results(pred, 0.3, 0.5, C)
+    kept0 = out[(out[:, 0] == 1) & (out[:, 7] == 0)][:, 1:5].astype(np.float32)
+    rows, _ = orc.candidates(pred[1], 0.3, C)
+    cand = rows[rows[:, 6] == 0][:, :4].astype(np.float32)
+    vals = np.unique(np.concatenate([c_box_iou(k[None, :], cand) for k in kept0[:20]]))
+    vals = vals[(vals > 0.3) & (vals < 0.7)]
+    picked = []
+    for t in vals:
+        up = np.nextafter(np.float32(t), np.float32(1))
+        if c_filter_results(pred, 0.3, float(t), C).shape[0] != c_filter_results(pred, 0.3, float(up), C).shape[0]:
+            picked.append(t)
+        if len(picked) == 3:
+            break
+    assert len(picked) == 3
+    thresholds = []
+    for t in picked:
+        t = np.float32(t)
+        thresholds += [t, np.nextafter(t, np.float32(0)), np.nextafter(t, np.float32(1))]
+    thresholds += [np.float32(0.5), np.float32(0.25), np.float32(1.0), np.nextafter(np.float32(1), np.float32(2)),
+                   np.float32(1e-3), np.float32(0.0), np.float32(-0.5), np.float32(1e-40), np.float32(np.inf),
+                   np.float32(np.nan)]
+    kept = set()
+    for t in thresholds:
+        want = c_filter_results(pred, 0.3, float(t), C)
+        got = hip_filter(pred, 0.3, float(t), C)
+        if want.shape[0] == 0:
+            assert isinstance(got, int) and got == 0
+        else:
+            assert_bit_equal(got.cpu().numpy(), want, f"nms threshold {t!r}")
+        kept.add(want.shape[0])
+    assert len(kept) >= 6, "the thresholds did not change the result: the case tests nothing"

@@ -87,6 +87,38 @@ __device__ __forceinline__ float iou_tame(float4 p, float a1, float4 q, float a2
     return __fdiv_rn(inter, __fsub_rn(__fadd_rn(a1, a2), inter));
 }
 
+// `iou < thresh` without the division.  The reference compares the fp32 quotient
+// fl(inter / uni) with thresh.  For uni > 0 and a positive normal thresh, rounding to
+// nearest is monotone, so fl(inter / uni) < thresh exactly when the true quotient lies
+// below mid = (pred(thresh) + thresh) / 2, i.e. when inter < uni * mid.  mid has 25
+// significant bits and uni 24: the product is exact in float64, so the comparison is
+// exact.  (A tie, inter == uni * mid, cannot happen: mid's last bit is set, so the product
+// needs 25 significant bits and inter has 24.)  A float64 multiply and compare take the
+// place of the IEEE division's dozen instructions.  Pairs with uni <= 0 or NaN are flagged
+// and their word is recomputed with the division.
+__device__ __forceinline__ bool below_tame(float4 p, float a1, float4 q, float a2, double mid, bool& flagged) {
+    const float ix1 = vmax(p.x, q.x), iy1 = vmax(p.y, q.y);
+    const float ix2 = vmin(p.z, q.z), iy2 = vmin(p.w, q.w);
+    const float iw = vmax(__fadd_rn(__fsub_rn(ix2, ix1), 1.0f), 0.0f);
+    const float ih = vmax(__fadd_rn(__fsub_rn(iy2, iy1), 1.0f), 0.0f);
+    const float inter = __fmul_rn(iw, ih);
+    const float uni = __fsub_rn(__fadd_rn(a1, a2), inter);
+    flagged |= !(uni > 0.f);
+    return (double)inter < (double)uni * mid;
+}
+
+// mid for below_tame, or 0 when thresh is not a positive normal number (the kernels then
+// keep the division)
+static double thresh_midpoint(float t) {
+    if (!(t >= 1.17549435e-38f) || !(t <= 3.402823466e38f)) return 0.0;
+    uint32_t u;
+    memcpy(&u, &t, 4);
+    --u;
+    float prev;
+    memcpy(&prev, &u, 4);
+    return ((double)prev + (double)t) * 0.5;
+}
+
 // ---------------------------------------------------------------- box_iou
 __global__ void __launch_bounds__(256)
 box_iou_kernel(const float* __restrict__ b1, int n1, const float* __restrict__ b2, int m,
@@ -452,7 +484,7 @@ nms_mask_kernel(const unsigned long long* __restrict__ keys, int key_stride, int
                 const int* __restrict__ seg_start, const int* __restrict__ seg_end,
                 const int* __restrict__ tile_base, const int* __restrict__ mask_off,
                 const int* __restrict__ total_tiles, const float4* __restrict__ boxes, int box_stride,
-                float thresh, unsigned long long* __restrict__ mask, size_t mask_stride) {
+                float thresh, double mid, unsigned long long* __restrict__ mask, size_t mask_stride) {
     __shared__ float4 colbox[4][64];
     __shared__ float colarea[4][64];
     const int b = blockIdx.y;
@@ -484,16 +516,32 @@ nms_mask_kernel(const unsigned long long* __restrict__ keys, int key_stride, int
         colbox[wave][lane] = col;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        const int ncol = min(64, n - j0);
+        const int ncol = __builtin_amdgcn_readfirstlane(min(64, n - j0));
         unsigned long long word = 0;
         if (__ballot(!box_tame(mine) || !box_tame(col)) == 0ull) {
             colarea[wave][lane] = box_area(col);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             const float my_area = box_area(mine);
-            for (int jj = 0; jj < ncol; ++jj) {
-                const bool sup = !(iou_tame(mine, my_area, colbox[wave][jj], colarea[wave][jj]) < thresh);
-                word |= (unsigned long long)sup << jj;
+            bool flagged = false;
+            if (mid != 0.0) {
+                auto pair = [&](int jj) {
+                    const bool sup = !below_tame(mine, my_area, colbox[wave][jj], colarea[wave][jj], mid, flagged);
+                    word |= (unsigned long long)sup << jj;
+                };
+                if (ncol == 64) {            // a full tile: constant trip count, four pairs' LDS reads in flight
+#pragma unroll 4
+                    for (int jj = 0; jj < 64; ++jj) pair(jj);
+                } else {
+                    for (int jj = 0; jj < ncol; ++jj) pair(jj);
+                }
+            }
+            if (mid == 0.0 || __ballot(flagged) != 0ull) {   // a union that is not positive: divide
+                word = 0;
+                for (int jj = 0; jj < ncol; ++jj) {
+                    const bool sup = !(iou_tame(mine, my_area, colbox[wave][jj], colarea[wave][jj]) < thresh);
+                    word |= (unsigned long long)sup << jj;
+                }
             }
         } else {
             for (int jj = 0; jj < ncol; ++jj) {
@@ -683,31 +731,40 @@ nms_scan_kernel(const int* __restrict__ seg_kept, int S, int* __restrict__ seg_o
 // ---------------------------------------------------------------- gather
 // Row = [image, x1, y1, x2, y2, objectness, class score, class index, y1]
 // (utilis.py:397-411 makes the 9th value alias ymin).
-__global__ void __launch_bounds__(64)
+// One lane per slot of the images' sorted key arrays.  Slot i of image b lies in the
+// segment of class c = class of key i; it is slot r = i - seg_start of that segment's kept
+// list and stands for an output row iff r < seg_kept.  (One workgroup per (image, class)
+// walked the longest kept list 64 rows at a time: 15 us for a 600-row list.)
+__global__ void __launch_bounds__(256)
 nms_gather_kernel(const unsigned long long* __restrict__ keys, int key_stride, int N, int C,
+                  const int* __restrict__ cand_count, int G,
                   const int* __restrict__ seg_start, const int* __restrict__ seg_kept,
                   const int* __restrict__ seg_off, const int* __restrict__ kept_pos,
                   const float4* __restrict__ boxes, const float* __restrict__ scores,
                   float* __restrict__ out) {
-    const int c = blockIdx.x, b = blockIdx.y;
-    const int nk = seg_kept[b * C + c];
-    if (nk == 0) return;
+    const int b = blockIdx.y;
+    int total = 0;
+    for (int g = 0; g < G; ++g) total += cand_count[(b * G + g) * CNT_STRIDE];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total || i >= N) return;
+    const unsigned long long* gk = keys + (size_t)b * key_stride;
+    const int pos = kept_pos[(size_t)b * N + i];
+    const int c = key_cls(gk[i]);
+    if (c >= C) return;
     const int s = seg_start[b * C + c];
-    const int off = seg_off[b * C + c];
-    const unsigned long long* gk = keys + (size_t)b * key_stride + s;
-    const int* kp = kept_pos + (size_t)b * N + s;
-    for (int r = threadIdx.x; r < nk; r += 64) {
-        unsigned long long k = gk[kp[r]];
-        int row = key_row(k);
-        float4 bx = boxes[(size_t)b * N + row];
-        float* o = out + (size_t)(off + r) * 9;
-        o[0] = (float)b;
-        o[1] = bx.x; o[2] = bx.y; o[3] = bx.z; o[4] = bx.w;
-        o[5] = key_obj(k);
-        o[6] = scores[(size_t)b * N + row];
-        o[7] = (float)c;
-        o[8] = bx.y;
-    }
+    const int r = i - s;
+    if (r < 0 || r >= seg_kept[b * C + c] || pos < 0 || s + pos >= total) return;
+    const unsigned long long k = gk[s + pos];
+    const int row = key_row(k);
+    if (row >= N) return;
+    const float4 bx = boxes[(size_t)b * N + row];
+    float* o = out + (size_t)(seg_off[b * C + c] + r) * 9;
+    o[0] = (float)b;
+    o[1] = bx.x; o[2] = bx.y; o[3] = bx.z; o[4] = bx.w;
+    o[5] = key_obj(k);
+    o[6] = scores[(size_t)b * N + row];
+    o[7] = (float)c;
+    o[8] = bx.y;
 }
 
 
@@ -863,13 +920,13 @@ static int run_filter_results(const float* pred, int B, int N, int D, int C, flo
                        w.tile_base, w.mask_off, w.total_tiles);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, B), dim3(256), 0, stream, w.keys, w.key_stride,
                        N, C, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles, w.boxes, 1,
-                       nms_thresh, w.mask, w.mask_stride);
+                       nms_thresh, thresh_midpoint(nms_thresh), w.mask, w.mask_stride);
     hipLaunchKernelGGL(nms_reduce_kernel, dim3(C, B), dim3(REDUCE_THREADS), 0, stream, N, C, w.seg_start, w.seg_end,
                        w.mask_off, w.mask, w.mask_stride, w.kept_pos, w.seg_kept);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, B * C, w.seg_off,
                        out_count);
-    hipLaunchKernelGGL(nms_gather_kernel, dim3(C, B), dim3(64), 0, stream, w.keys, w.key_stride, N, C,
-                       w.seg_start, w.seg_kept, w.seg_off, w.kept_pos, w.boxes, w.scores, out_rows);
+    hipLaunchKernelGGL(nms_gather_kernel, dim3((N + 255) / 256, B), dim3(256), 0, stream, w.keys, w.key_stride, N, C,
+                       w.cand_count, w.G, w.seg_start, w.seg_kept, w.seg_off, w.kept_pos, w.boxes, w.scores, out_rows);
     YA_CHECK_HIP(hipGetLastError());
     return YA_OK;
 }
@@ -953,7 +1010,7 @@ extern "C" int yolo_amd_filter_img_class(const float* rows8, int m, float cls, f
                        w.tile_base, w.mask_off, w.total_tiles);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(MASK_GRID_X, 1), dim3(256), 0, stream, w.keys, w.key_stride,
                        m, 1, w.seg_start, w.seg_end, w.tile_base, w.mask_off, w.total_tiles,
-                       reinterpret_cast<const float4*>(rows8), 2, nms_thresh, w.mask, w.mask_stride);
+                       reinterpret_cast<const float4*>(rows8), 2, nms_thresh, thresh_midpoint(nms_thresh), w.mask, w.mask_stride);
     hipLaunchKernelGGL(nms_reduce_kernel, dim3(1, 1), dim3(REDUCE_THREADS), 0, stream, m, 1, w.seg_start, w.seg_end,
                        w.mask_off, w.mask, w.mask_stride, w.kept_pos, w.seg_kept);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, stream, w.seg_kept, 1, w.seg_off,
