@@ -278,7 +278,9 @@ typedef struct {
     int act_ksteps;      /* IGEMM: depth of the activation tile in K steps (1, 2) */
     int lds_stages;      /* IGEMM: depth of the LDS ring                         */
     int waves;           /* waves per workgroup                                  */
-    int taps_per_stage;  /* PATCH: taps per weight stage (1 or 3)                */
+    int taps_per_stage;  /* PATCH: taps per shared weight stage (1 or 3); 9: every */
+                         /* wave stages its own channels' weights, one barrier per */
+                         /* nine taps                                              */
     int k_slices;        /* > 1: split reduction + finishing launch              */
 } yolo_amd_conv_choice;
 int yolo_amd_conv_query(const yolo_amd_conv_desc* desc, yolo_amd_conv_choice* out);

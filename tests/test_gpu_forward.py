@@ -244,7 +244,8 @@ PATCH_CASES = [
 ]
 
 
-@pytest.mark.parametrize("stg", ["1", "3", "3/256"], ids=["tap-stages", "row-stages", "row-stages-256ch"])
+@pytest.mark.parametrize("stg", ["1", "3", "3/256", "9"],
+                         ids=["tap-stages", "row-stages", "row-stages-256ch", "private-weight-rings"])
 @pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: c[0])
 def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     from gpu_helpers import conv_reference, run_conv
@@ -253,8 +254,8 @@ def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     wide = stg.endswith("/256")
     if wide and (cout + 127) // 128 * 128 % 256:
         pytest.skip("the 256-channel tile needs the padded channel count to be a multiple of 256")
-    if H % 13 and stg != "1":
-        pytest.skip("19 x 10 tiles exist with tap-deep weight stages only")
+    if H % 13 and stg not in ("1", "9"):
+        pytest.skip("19 x 10 tiles exist with tap-deep weight stages and with private weight rings")
     set_knob(monkeypatch, "YOLO_AMD_CONV3_STG", stg[0])
     set_knob(monkeypatch, "YOLO_AMD_CONV3_TC", "4" if wide else "2")
     r = gi.rs(case_seed(name))

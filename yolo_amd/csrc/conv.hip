@@ -150,6 +150,21 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// s_waitcnt vmcnt(n) for a count known only after unrolling (0..8)
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {
+    switch (n) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        case 5: wait_vmcnt<5>(); break;
+        case 6: wait_vmcnt<6>(); break;
+        case 7: wait_vmcnt<7>(); break;
+        default: wait_vmcnt<8>(); break;
+    }
+}
+
 // wait until at most `stages` of the youngest stages (PER loads each) are in flight
 template <int MAXS, int PER>
 __device__ __forceinline__ void wait_stages(int stages) {
@@ -645,12 +660,20 @@ struct Conv3Args {
 // TC = channel groups of 16 per wave: 2 (workgroup = 128 channels) or 4 (256 channels: a wave
 // then issues 24 MFMAs per tap for 6 + 4 fragment reads instead of 12 for 6 + 2; the weight
 // ring grows to 96 KiB, one workgroup of eight waves per CU, up to 256 registers).
-template <int WAVES, int STG = 1, int TC = 2, int TH = P3_TS, int TW = P3_TS>
+template <int WAVES, int STG = 1, int TC = 2, int TH = P3_TS, int TW = P3_TS, int RING = 3>
 __global__ void __launch_bounds__(64 * WAVES)
-    __attribute__((amdgpu_waves_per_eu(TC == 4 ? 2 : (WAVES == 4 ? 3 : 4), TC == 4 ? 2 : (WAVES == 4 ? 3 : 4))))
+    __attribute__((amdgpu_waves_per_eu((TC == 4 || (STG == 9 && RING == 4)) ? 2 : (WAVES == 4 ? 3 : 4),
+                                       (TC == 4 || (STG == 9 && RING == 4)) ? 2 : (WAVES == 4 ? 3 : 4))))
 conv3x3_patch_kernel(const Conv3Args a) {
-    static_assert(STG == 1 || (STG == 3 && WAVES == 8), "row-deep weight stages exist for the eight-wave form");
+    static_assert(STG == 1 || ((STG == 3 || STG == 9) && WAVES == 8), "row-deep weight stages exist for the eight-wave form");
     static_assert(TC == 2 || (TC == 4 && WAVES == 8 && STG == 3), "the 256-channel tile exists for eight waves, row-deep stages");
+    // STG = 9: every wave stages the weights of ITS 32 channels itself, into a ring of its own
+    // (three taps deep, 2 KiB per tap; the two waves of a channel group each hold a copy), so
+    // weights never wait for another wave: counted vmcnt waits only, and the workgroup meets
+    // at a barrier once per 32-channel chunk (nine taps), for the shared input patch.
+    constexpr bool PRIV = STG == 9;
+    constexpr int PRIV_R = RING;                   // taps held per private ring (2, 3 or 4)
+    static_assert(!PRIV || (PRIV_R >= 2 && PRIV_R <= 4), "private ring depth");
     constexpr int CT = 64 * TC;                    // channels per workgroup
     constexpr int WSTAGE = CT * 64;                // bytes of one (chunk, tap) weight stage: CT channels x 32 bf16
     static_assert(TW + 2 <= 16, "a patch row must fit the 16 slots of a plane row");
@@ -672,7 +695,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
     // memory runs under the matrix work instead of after it.
     constexpr bool RPRE = WAVES == 8 && STG == 1 && TH == 13 && TW == 13;
     constexpr int TILE_BYTES = P3_TP * 16 * CT * 2;
-    constexpr int RING_BYTES = 2 * STG * WSTAGE;            // two stages of STG taps
+    constexpr int RING_BYTES = PRIV ? WAVES * PRIV_R * 2048 : 2 * STG * WSTAGE;   // two stages of STG taps
     __shared__ __attribute__((aligned(1024))) char lds_all[RING_BYTES + 2 * P3_PATCH + (RPRE ? TILE_BYTES - P3_PATCH : 0)];
     static_assert(sizeof(lds_all) >= TILE_BYTES, "the epilogue tile reuses this memory");
     char* const wring = lds_all;
@@ -762,13 +785,88 @@ conv3x3_patch_kernel(const Conv3Args a) {
 
 #pragma unroll
     for (int ii = 0; ii < PP; ++ii) issue_patch(0, ii);
-    issue_w(0, 0, 0);
+    if constexpr (!PRIV) issue_w(0, 0, 0);
     stamp(1);
     bool patch_behind = false;                 // a patch load was issued after the weights now awaited
     // the vector epilogue will want the residual tile in LDS (all 128 channels of the tile exist)
     const bool res_pre = RPRE && (a.prio & 2) && a.res && !a.dst_fp32 && (a.Cout & 7) == 0 && n0 + CT <= a.Cout;
     int buf = 0;
-    if constexpr (STG == 3) {
+    if constexpr (PRIV) {
+        static_assert(!PRIV || (PP <= 3 && TC == 2), "private weight rings: 128-channel workgroups");
+        char* const myring = wring + w * (PRIV_R * 2048);
+        int woffp[2];
+        {
+            const int qw = (lane & 3) ^ chunk_swizzle<32>(lane >> 2);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) woffp[i] = (n0 + cg * 32 + i * 16 + (lane >> 2)) * 32 + qw * 8;
+        }
+        auto issue_wp = [&](int chunk, int tap, int slot) {
+            const int delta = tap * wstep_tap + chunk * wstep_chunk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) lds_dma16(a.wgt + (woffp[i] + delta), myring + slot * 2048 + i * 1024);
+        };
+        const int wfragp = slot_of<32>(r, q) * 16;
+#pragma unroll
+        for (int t = 0; t < PRIV_R - 1; ++t) issue_wp(0, t, t);
+        int slot0 = 0;                             // ring slot of this chunk's tap 0
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const char* pb = lds + ((NCH - 1 - chunk) & 1) * P3_PATCH;
+            const bool more_chunks = chunk + 1 < NCH;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                constexpr int dummy = 0; (void)dummy;
+                const int kh = tap / 3, kw = tap - 3 * (tap / 3);
+                // Loads are answered in issue order.  Younger than this tap's weights (issued
+                // PRIV_R - 1 taps ago, the last thing that tap issued) is what the taps since
+                // then issued: two weight pieces each while there were taps left to fetch for,
+                // and one patch piece during the first PP taps of a chunk that has a successor.
+                {
+                    int n_more = 0, n_last = 0;
+#pragma unroll
+                    for (int u = tap - PRIV_R + 2; u <= tap - 1; ++u) {
+                        n_more += 2 + ((u >= 0 && u < PP) ? 1 : 0);
+                        n_last += (u + PRIV_R - 1 <= 8) ? 2 : 0;
+                    }
+                    wait_vmcnt_upto(more_chunks ? n_more : n_last);
+                }
+                if (tap == 0) {
+                    // every wave's pieces of this chunk's patch are older than the weights it
+                    // has just waited for; behind the barrier nobody reads the other patch
+                    // buffer any more, so the next chunk's pieces may overwrite it
+                    __builtin_amdgcn_s_barrier();
+                }
+                asm volatile("" ::: "memory");
+                if (tap < PP && more_chunks) issue_patch(chunk + 1, tap);
+                {
+                    // slot of tap t of this chunk = (slot0 + t) mod PRIV_R
+                    int sl = slot0 + (tap + PRIV_R - 1) % PRIV_R;
+                    if (sl >= PRIV_R) sl -= PRIV_R;
+                    if (tap + PRIV_R - 1 < 9) issue_wp(chunk, tap + PRIV_R - 1, sl);
+                    else if (more_chunks) issue_wp(chunk + 1, tap + PRIV_R - 1 - 9, sl);
+                }
+                const int colb = ((r + kw + TW * kh) & 15) * 16 + kh * 256;
+                int cur = slot0 + tap % PRIV_R;
+                if (cur >= PRIV_R) cur -= PRIV_R;
+                const char* ws = myring + cur * 2048 + wfragp;
+                bf16x8 wf[2], xf[6];
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
+#pragma unroll
+                for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
+                if (a.prio & 1) __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                for (int tp = 0; tp < 6; ++tp) {
+                    if (tp >= ntp) break;
+#pragma unroll
+                    for (int tc = 0; tc < 2; ++tc)
+                        acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+                }
+                if (a.prio & 1) __builtin_amdgcn_s_setprio(0);
+            }
+            slot0 += 9 % PRIV_R;
+            if (slot0 >= PRIV_R) slot0 -= PRIV_R;
+        }
+    } else if constexpr (STG == 3) {
         // Ring slots 0-2 and 3-5 hold the three taps of the current and of the next
         // kernel row.  At the row's barrier everything issued so far has landed (full
         // wait); during the row each tap issues the matching tap of the next row into
@@ -1779,13 +1877,20 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
         c.bm = th * tw; c.bn = 128; c.bk = 32;
         if (th != 13) {
             // the 21-row patch buffers leave room for a tap-deep weight ring only
-            // (64 KiB, two workgroups per CU)
-            c.stg = 1; c.waves = 8;
+            // (64 KiB, two workgroups per CU), or for private rings two taps deep (80 KiB)
+            c.stg = env_int("YOLO_AMD_CONV3_STG", 9) == 9 ? 9 : 1; c.waves = 8;
             *out = c;
             return YA_OK;
         }
-        c.stg = env_int("YOLO_AMD_CONV3_STG", 3) == 3 ? 3 : 1;
-        c.waves = env_int("YOLO_AMD_CONV3_WAVES", (c.stg == 3 || p3_groups <= 1536) ? 8 : 4) == 8 ? 8 : 4;
+        {
+            // Private weight rings (9) where the reduction is long (>= 256 input channels: the
+            // 26x26 and 13x13 maps, 54.9 against 60.9 us on 512 -> 1024 @ 13x13, 3 % on 26x26);
+            // row-deep shared stages (3) on the short reductions of the 52x52 and 104x104 maps,
+            // where the two measure the same within 2 %.
+            const int stg = env_int("YOLO_AMD_CONV3_STG", d.c0 >= 256 ? 9 : 3);
+            c.stg = stg == 9 ? 9 : (stg == 3 ? 3 : 1);
+        }
+        c.waves = env_int("YOLO_AMD_CONV3_WAVES", (c.stg >= 3 || p3_groups <= 1536) ? 8 : 4) == 8 ? 8 : 4;
         if (c.waves == 4) c.stg = 1;
         // 256-channel workgroups (one per CU, 24 MFMAs per 10 fragment reads instead of 12 per 8):
         // measured no faster on 26x26 (55.4 against 56.5 us) and slower on 52x52 and 13x13
@@ -1808,7 +1913,7 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
     c.amul = (amul == 2 && BK == 32 && c.nstage == 2 && d.c0 % 64 == 0 && d.c1 % 64 == 0) ? 2 : 1;
     if (c.amul == 1) {
         // instantiated ring depths per tile shape
-        const bool deep3 = (BK == 32 && BN != 32) || (BN == 128 && BK == 64);
+        const bool deep3 = (BK == 32 && BN != 32) || (BN >= 64 && BK == 64);
         const bool deep4 = !(BN == 32 && BK == 32);
         if (!((c.nstage == 3 && deep3) || (c.nstage == 4 && deep4))) c.nstage = 2;
     }
@@ -1878,10 +1983,18 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
 #ifdef YOLO_AMD_DEV_TRACE
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
 #endif
-        if (c.th == 19)
+        if (c.th == 19 && c.stg == 9)
+            hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 19, 10, 2>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.th == 19)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 1, 2, 19, 10>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.bn == 256)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3, 4>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.waves == 8 && c.stg == 9 && env_int("YOLO_AMD_CONV3_RING", 3) == 4)
+            hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 13, 13, 4>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.waves == 8 && c.stg == 9 && env_int("YOLO_AMD_CONV3_RING", 3) == 2)
+            hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 13, 13, 2>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.waves == 8 && c.stg == 9)
+            hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.waves == 8 && c.stg == 3)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.waves == 8)
@@ -1951,6 +2064,7 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         else launch_igemm<128, 128, 32, 2, 2>(a, stream);
     } else if (BN == 64 && BK == 64) {
         if (ns == 4) launch_igemm<128, 64, 64, 2, 4>(a, stream);
+        else if (ns == 3) launch_igemm<128, 64, 64, 2, 3>(a, stream);
         else launch_igemm<128, 64, 64, 2, 2>(a, stream);
     } else if (BN == 64 && BK == 32) {
         if (ns == 3) launch_igemm<128, 64, 32, 2, 3>(a, stream);
