@@ -75,9 +75,9 @@ def test_conv_query_reports_the_kernel_without_a_gpu():
     assert q(desc(32, 416, 3, 32, 3, 1, first=1))["kernel"] == "first"
     assert q(desc(32, 208, 32, 64, 3, 1))["kernel"] == "thin"
     c = q(desc(32, 26, 256, 512, 3, 1))
-    assert (c["kernel"], c["waves"], c["taps_per_stage"]) == ("patch", 8, 9)    # long reduction: private weight rings
+    assert (c["kernel"], c["waves"], c["taps_per_stage"]) == ("patch", 8, 9)    # private weight rings
     c = q(desc(32, 52, 128, 256, 3, 1))
-    assert (c["kernel"], c["waves"], c["taps_per_stage"]) == ("patch", 8, 3)    # short reduction: row-deep shared stages
+    assert (c["kernel"], c["waves"], c["taps_per_stage"]) == ("patch", 8, 9)
     c = q(desc(32, 38, 256, 512, 3, 1))                                   # 608: 19 * 2^n maps take 19 x 10 tiles
     assert (c["kernel"], c["bm"], c["taps_per_stage"]) == ("patch", 190, 9)
     assert q(desc(32, 40, 256, 512, 3, 1))["kernel"] == "igemm"          # 320: no tile shape for 10 * 2^n maps

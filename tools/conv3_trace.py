@@ -27,7 +27,7 @@ def main():
     d, keep, flops, byts = cb.make_desc(a.batch, *spec[1:], dev)
     zero = torch.zeros(1024, dtype=torch.uint8, device=dev)
     stream = _lib.current_stream_ptr(dev)
-    trace = torch.zeros(1 << 16, dtype=torch.int64, device=dev)
+    trace = torch.zeros(1 << 18, dtype=torch.int64, device=dev)
     for _ in range(3):
         check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), stream), "conv")
     os.environ["YOLO_AMD_CONV3_TRACE"] = hex(trace.data_ptr())
@@ -67,6 +67,28 @@ def main():
         first_on_cu[members[np.argmin(t[members, 0])]] = True
     print(f"  K loop of the workgroup that started first on its CU: {kloop[first_on_cu].mean():.1f}, of the others: "
           f"{kloop[~first_on_cu].mean():.1f}")
+    # turnover on a CU: what lies between one workgroup's stores and its successor's K loop
+    life = t[:, 3] - t[:, 0]
+    print(f"  all workgroups: set-up {np.mean(t[:, 1] - t[:, 0]):.2f}  K loop {kloop.mean():.2f}  "
+          f"epilogue {np.mean(t[:, 3] - t[:, 2]):.2f}  lifetime {life.mean():.2f} us")
+    if raw[:, 5].max() > 0:
+        t5 = raw[:, 5].astype(np.float64) / 100.0 - t0
+        t6 = raw[:, 6].astype(np.float64) / 100.0 - t0
+        print(f"  epilogue: K loop done -> residual tile in LDS {np.mean(t5 - t[:, 2]):.2f}, -> output tile in LDS "
+              f"{np.mean(t6 - t5):.2f}, -> stores issued {np.mean(t[:, 3] - t6):.2f} us")
+    gaps, busy2 = [], []
+    for k in range(len(keys)):
+        members = np.nonzero(inv == k)[0]
+        members = members[np.argsort(t[members, 0])]
+        ends = np.sort(t[members, 3])
+        # the i-th start on this CU (i >= 2) follows the (i-2)-th end: two slots per CU
+        for i in range(2, len(members)):
+            gaps.append(t[members[i], 0] - ends[i - 2])
+        span = t[members, 3].max() - t[members, 0].min()
+        busy2.append(np.sum(t[members, 2] - t[members, 1]) / (2 * span) if span > 0 else 0)
+    if gaps:
+        print(f"  successor starts {np.mean(gaps):.2f} us after a slot's stores were issued (median {np.median(gaps):.2f}); "
+              f"share of the two slots' time spent inside K loops: {np.mean(busy2):.2f}")
     order = np.argsort(t[:, 0])
     first_round = t[order[: min(n, 512)]]
     later = t[order[512:]] if n > 512 else None

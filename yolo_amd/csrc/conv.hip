@@ -145,6 +145,15 @@ __device__ __forceinline__ void tile_put(char* lds, int slot, int chl, float v[4
     *p = pk;
 }
 
+// max(v, slope*v) for 0 < slope <= 1: one multiply and one bare v_max_f32 (fmaxf / fmed3
+// put a canonicalising v_max(v, v) in front of it)
+__device__ __forceinline__ float leaky_max(float v, float slope) {
+    float r;
+    const float sv = slope * v;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+    return r;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -647,7 +656,8 @@ struct Conv3Args {
     int tiles_n;                       // channel tiles
     long long* trace;                  // development aid, always null unless the file is built with -DYOLO_AMD_DEV_TRACE
                                        // (then YOLO_AMD_CONV3_TRACE=<device address>): per workgroup eight words:
-                                       // 100 MHz timestamps (start, K loop entered, K loop done, stores issued), XCC_ID << 32 | HW_ID
+                                       // 100 MHz timestamps (start, K loop entered, K loop done, stores issued), XCC_ID << 32 | HW_ID,
+                                       // then two more timestamps (residual tile landed, output tile complete in LDS)
     int prio;                          // raise the wave priority over the MFMA groups (about 1 %; YOLO_AMD_CONV3_PRIO=0 turns it off)
 };
 
@@ -777,11 +787,15 @@ conv3x3_patch_kernel(const Conv3Args a) {
             lds_dma16(a.wgt + (woff[i] + delta), wring + buf * WSTAGE + (w * WP + i) * 1024);
     };
 
+    // the accumulators start from the bias (one add less per output in the epilogue, and the
+    // bias is fetched under the first loads instead of after the last MFMA)
     f32x4 acc[TC][NTP];
 #pragma unroll
-    for (int tc = 0; tc < TC; ++tc)
+    for (int tc = 0; tc < TC; ++tc) {
+        const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + cg * 16 * TC + tc * 16 + (lane >> 4) * 4);
 #pragma unroll
-        for (int tp = 0; tp < NTP; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tp = 0; tp < NTP; ++tp) acc[tc][tp] = bs;
+    }
 
 #pragma unroll
     for (int ii = 0; ii < PP; ++ii) issue_patch(0, ii);
@@ -791,9 +805,35 @@ conv3x3_patch_kernel(const Conv3Args a) {
     // the vector epilogue will want the residual tile in LDS (all 128 channels of the tile exist)
     const bool res_pre = RPRE && (a.prio & 2) && a.res && !a.dst_fp32 && (a.Cout & 7) == 0 && n0 + CT <= a.Cout;
     int buf = 0;
+    // Private rings three taps deep: each wave fetches ITS part of the residual tile (<= 6 pixel
+    // groups x 32 channels = six 1 KiB pieces) itself, into memory nobody else reads, so that
+    // nothing waits for a barrier, and early, during the last 32-channel chunk: pieces 0-1 at
+    // its first tap into this wave's 2 KiB of the idle patch buffer, pieces 2-3 and 4-5 at the
+    // last two taps into the ring slots those taps no longer fetch weights for.  Layout of a
+    // piece: 16 pixels x 64 B, the 16-byte chunk c of pixel p at position c ^ ((p >> 2) & 3)
+    // (conflict-free 8-byte reads).
+    constexpr bool OWN_RES = PRIV && PRIV_R == 3 && 2 * P3_PATCH >= P3_PATCH + WAVES * 2048 && NTP <= 6;
+    char* const myring = wring + w * (PRIV_R * 2048);
+    const bool own_res = OWN_RES && a.res && !a.dst_fp32 && (a.Cout & 7) == 0;
+    auto res_at = [&](int tp) -> char* {
+        return tp < 2 ? lds + P3_PATCH + w * 2048 + tp * 1024 : myring + ((tp - 2) >> 1) * 2048 + (tp & 1) * 1024;
+    };
+    auto res_piece = [&](int tp) {
+        // (the addresses are worked out where the piece is issued, three times per tile: hoisted
+        // out of the K loop they would cost registers the loop does not have)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int slot = (tp0 + tp) * 16 + (ln >> 2);
+        const int ty = slot / TW, tx = slot - ty * TW;
+        const bool okp = tp < ntp && slot < P3_NPIX && oy0 + ty < a.H && ox0 + tx < a.W;
+        const int ch = n0 + cg * 32 + (((ln & 3) ^ ((ln >> 4) & 3)) * 8);
+        const __bf16* src = (okp && ch + 8 <= a.Cout)
+                                ? a.res + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + ch)
+                                : a.zero;
+        lds_dma16(src, res_at(tp));
+    };
     if constexpr (PRIV) {
         static_assert(!PRIV || (PP <= 3 && TC == 2), "private weight rings: 128-channel workgroups");
-        char* const myring = wring + w * (PRIV_R * 2048);
         int woffp[2];
         {
             const int qw = (lane & 3) ^ chunk_swizzle<32>(lane >> 2);
@@ -820,14 +860,17 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 // PRIV_R - 1 taps ago, the last thing that tap issued) is what the taps since
                 // then issued: two weight pieces each while there were taps left to fetch for,
                 // and one patch piece during the first PP taps of a chunk that has a successor.
+                // (In the last chunk the residual pieces take the place of the patch pieces:
+                // two each at taps 0, 7 and 8.)
                 {
-                    int n_more = 0, n_last = 0;
+                    int n_more = 0, n_last = 0, n_res = 0;
 #pragma unroll
                     for (int u = tap - PRIV_R + 2; u <= tap - 1; ++u) {
                         n_more += 2 + ((u >= 0 && u < PP) ? 1 : 0);
                         n_last += (u + PRIV_R - 1 <= 8) ? 2 : 0;
+                        n_res += ((u + PRIV_R - 1 <= 8) ? 2 : 0) + ((u == 0 || u == 7) ? 2 : 0);
                     }
-                    wait_vmcnt_upto(more_chunks ? n_more : n_last);
+                    wait_vmcnt_upto(more_chunks ? n_more : (own_res ? n_res : n_last));
                 }
                 if (tap == 0) {
                     // every wave's pieces of this chunk's patch are older than the weights it
@@ -837,6 +880,13 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 }
                 asm volatile("" ::: "memory");
                 if (tap < PP && more_chunks) issue_patch(chunk + 1, tap);
+                if constexpr (OWN_RES) {
+                    if (own_res && !more_chunks && (tap == 0 || tap == 7 || tap == 8)) {
+                        const int first = tap == 0 ? 0 : (tap == 7 ? 2 : 4);
+                        res_piece(first);
+                        res_piece(first + 1);
+                    }
+                }
                 {
                     // slot of tap t of this chunk = (slot0 + t) mod PRIV_R
                     int sl = slot0 + (tap + PRIV_R - 1) % PRIV_R;
@@ -989,12 +1039,40 @@ conv3x3_patch_kernel(const Conv3Args a) {
             if (oy0 + ty >= a.H || ox0 + tx >= a.W) return -1;         // a tile that hangs over the edge
             return ((long long)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
         };
-        wait_vmcnt<0>();
+        // (a wave's own part of the residual tile is already on its way: see own_res above)
+        const float slope = a.leaky ? 0.1f : 1.0f;
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+#pragma unroll
+            for (int tp = 0; tp < NTP; ++tp) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[tc][tp][e] = leaky_max(acc[tc][tp][e], slope);
+            }
+        }
+        if (!own_res) wait_vmcnt<0>();
+        if (own_res) {
+#pragma unroll
+            for (int tp = 0; tp < NTP; ++tp) {
+                // the pieces went out in pairs, in this order
+                if (tp == 0) wait_vmcnt<4>();
+                if (tp == 2) wait_vmcnt<2>();
+                if (tp == 4) wait_vmcnt<0>();
+                if (tp >= ntp) break;
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc) {
+                    const int c = (tc * 2 + (q >> 1)) ^ ((r >> 2) & 3);
+                    const bf16x4 rr = *reinterpret_cast<const bf16x4*>(res_at(tp) + r * 64 + c * 16 + (q & 1) * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[tc][tp][e] += (float)rr[e];
+                }
+            }
+        }
         __syncthreads();
-        if (a.res && !res_pre) {
+        if (a.res && !res_pre && !own_res) {
             tile_load_residual<NSLOT, CT, 64 * WAVES>(rtile, a.res, a.zero, a.Cout, n0, w, lane, pix);
             __syncthreads();
         }
+        stamp(5);
 #pragma unroll
         for (int tp = 0; tp < NTP; ++tp) {
             if (tp >= ntp) break;
@@ -1002,18 +1080,12 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
             for (int tc = 0; tc < TC; ++tc) {
                 const int chl = cg * 16 * TC + tc * 16 + cq;
-                const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + chl);
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = acc[tc][tp][e] + bs[e];
-                    if (a.leaky) x = x > 0.f ? x : 0.1f * x;
-                    v[e] = x;
-                }
-                tile_put<CT>(rtile, slot, chl, v, a.res != nullptr);
+                float v[4] = {acc[tc][tp][0], acc[tc][tp][1], acc[tc][tp][2], acc[tc][tp][3]};
+                tile_put<CT>(rtile, slot, chl, v, a.res != nullptr && !own_res);
             }
         }
         __syncthreads();
+        stamp(6);
         tile_store<NSLOT, CT, 64 * WAVES>(rtile, (__bf16*)a.dst, a.Cout, n0, pix);
         stamp(3);
         return;
@@ -1029,12 +1101,11 @@ conv3x3_patch_kernel(const Conv3Args a) {
         for (int tc = 0; tc < TC; ++tc) {
             const int ch = n0 + cg * 16 * TC + tc * 16 + cq;
             if (ch >= a.Cout) continue;
-            const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + ch);
             const size_t o = m * a.Cout + ch;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (ch + e >= a.Cout) break;
-                float x = acc[tc][tp][e] + bs[e];
+                float x = acc[tc][tp][e];
                 if (a.leaky) x = x > 0.f ? x : 0.1f * x;
                 if (a.res) x += (float)a.res[o + e];
                 if (a.dst_fp32) ((float*)a.dst)[o + e] = x;
@@ -1061,15 +1132,6 @@ conv3x3_patch_kernel(const Conv3Args a) {
 // bound by its 64-byte-per-pixel output stream.
 constexpr uint32_t kRawBufferFlags = 0x00020000u;   // untyped 32-bit raw buffer descriptor word 3
 constexpr int FIRST_TH = 8, FIRST_TW = 32, FIRST_PH = FIRST_TH + 2, FIRST_PW = FIRST_TW + 2;
-
-// max(v, slope*v) for 0 < slope <= 1: one multiply and one bare v_max_f32 (fmaxf / fmed3
-// put a canonicalising v_max(v, v) in front of it)
-__device__ __forceinline__ float leaky_max(float v, float slope) {
-    float r;
-    const float sv = slope * v;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
-    return r;
-}
 
 // two fp32 -> one dword of two bf16 (one v_cvt_pk_bf16_f32; converting element by element
 // costs a conversion and a v_perm per value)
@@ -1883,11 +1945,11 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
             return YA_OK;
         }
         {
-            // Private weight rings (9) where the reduction is long (>= 256 input channels: the
-            // 26x26 and 13x13 maps, 54.9 against 60.9 us on 512 -> 1024 @ 13x13, 3 % on 26x26);
-            // row-deep shared stages (3) on the short reductions of the 52x52 and 104x104 maps,
-            // where the two measure the same within 2 %.
-            const int stg = env_int("YOLO_AMD_CONV3_STG", d.c0 >= 256 ? 9 : 3);
+            // Private weight rings (9: counted waits, one barrier per nine taps, the wave's own
+            // residual pieces fetched during the last chunk) against row-deep shared stages (3):
+            // 75.0 / 79.1 us on 64 -> 128 @ 104x104, 62.2 / 65.1 on 128 -> 256 @ 52x52, 54.8 / 57.9
+            // on 256 -> 512 @ 26x26, 56.0 / 61.8 on 512 -> 1024 @ 13x13.
+            const int stg = env_int("YOLO_AMD_CONV3_STG", 9);
             c.stg = stg == 9 ? 9 : (stg == 3 ? 3 : 1);
         }
         c.waves = env_int("YOLO_AMD_CONV3_WAVES", (c.stg >= 3 || p3_groups <= 1536) ? 8 : 4) == 8 ? 8 : 4;
