@@ -898,12 +898,13 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 int cur = slot0 + tap % PRIV_R;
                 if (cur >= PRIV_R) cur -= PRIV_R;
                 const char* ws = myring + cur * 2048 + wfragp;
-                bf16x8 wf[2], xf[6];
+                bf16x8 wf[2];
 #pragma unroll
                 for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
+                bf16x8 xf[6];
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
-                if (a.prio & 1) __builtin_amdgcn_s_setprio(2);
+                __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) {
                     if (tp >= ntp) break;
@@ -911,7 +912,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     for (int tc = 0; tc < 2; ++tc)
                         acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
                 }
-                if (a.prio & 1) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
             }
             slot0 += 9 % PRIV_R;
             if (slot0 >= PRIV_R) slot0 -= PRIV_R;
@@ -1048,6 +1049,51 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[tc][tp][e] = leaky_max(acc[tc][tp][e], slope);
             }
+        }
+        if constexpr (OWN_RES) {
+            // The wave's outputs take the place of its residual pieces (same 16 pixels x 64 B
+            // layout, in the wave's own LDS), are read back as whole 16-byte chunks and stored
+            // by the wave itself: no workgroup barrier anywhere in this epilogue, every wave
+            // leaves as soon as its own pixels are out.  A 64-byte run per pixel and wave; the
+            // wave of the neighbouring channel group writes the other half of the line.
+#pragma unroll
+            for (int tp = 0; tp < NTP; ++tp) {
+                if (own_res) {                   // the pieces went out in pairs, in this order
+                    if (tp == 0) wait_vmcnt<4>();
+                    if (tp == 2) wait_vmcnt<2>();
+                    if (tp == 4) wait_vmcnt<0>();
+                }
+                if (tp >= ntp) break;
+#pragma unroll
+                for (int tc = 0; tc < TC; ++tc) {
+                    const int c = (tc * 2 + (q >> 1)) ^ ((r >> 2) & 3);
+                    bf16x4* p = reinterpret_cast<bf16x4*>(res_at(tp) + r * 64 + c * 16 + (q & 1) * 8);
+                    float v[4] = {acc[tc][tp][0], acc[tc][tp][1], acc[tc][tp][2], acc[tc][tp][3]};
+                    if (own_res) {
+                        const bf16x4 rr = *p;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+                    }
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[e];
+                    *p = pk;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            stamp(6);
+#pragma unroll
+            for (int tp = 0; tp < NTP; ++tp) {
+                if (tp >= ntp) break;
+                const long long pm = pix((tp0 + tp) * 16 + (lane >> 2));
+                const int ch = n0 + cg * 32 + (((lane & 3) ^ ((lane >> 4) & 3)) * 8);
+                const bf16x8 val = *reinterpret_cast<const bf16x8*>(res_at(tp) + lane * 16);
+                if (pm >= 0 && ch + 8 <= a.Cout)
+                    *reinterpret_cast<bf16x8*>((__bf16*)a.dst + (pm * a.Cout + ch)) = val;
+            }
+            stamp(3);
+            return;
         }
         if (!own_res) wait_vmcnt<0>();
         if (own_res) {
