@@ -237,6 +237,8 @@ PATCH_CASES = [
     ("p3_c128_n255_fp32", 2, 13, 128, 255, False, False, True),
     ("p3_c64_n128_h52", 1, 52, 64, 128, True, False, False),
     ("p3_c64_n768_h26_b5", 5, 26, 64, 768, True, True, False),     # three 256-channel tiles, or six of 128
+    ("p3_c64_n192_partial_channel_tile", 2, 13, 64, 192, True, True, False),   # the second tile holds 64 real channels
+    ("p3_c32_n200_partial_chunk", 1, 26, 32, 200, True, True, False),          # ... 72: a wave's 32 channels end mid-way
     # 19 * 2^n maps (608-pixel inputs): 19 x 10 tiles, the last tile of a row hangs over the edge
     ("p3_19x10_c64_n128_h19", 2, 19, 64, 128, True, True, False),
     ("p3_19x10_c96_n256_h38", 3, 38, 96, 256, True, True, False),
