@@ -232,6 +232,8 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra pipelined measurement")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-launch event passes")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight per GPU, each on a HIP stream of its own (1: one batch after the other)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -266,6 +268,32 @@ def main():
     flops_per_batch = sum(2.0 * B * o["Ho"] * o["Wo"] * o["ent"]["cout"] * o["ent"]["cin"] *
                           o["ent"]["k"] ** 2 for o in plan.ops)
 
+    from yolo_amd.utilis import filter_results_async
+    F = max(1, args.in_flight)
+    from yolo_amd.harness import concurrent_streams
+    # (streams that do not share a hardware queue: two that do would run one after the other)
+    lanes = list(concurrent_streams(device)) if F == 2 else [torch.cuda.Stream(device=device) for _ in range(F)]
+    xs = [x] + [torch.from_numpy(gi.images(1000 + rank * F + s, B, H)).to(device) for s in range(1, F)]
+    pending = [None] * F
+
+    def flight_step(i):
+        """One pass of the hot path over one batch: model(x) -> filter_results, queued on
+        stream i % F behind that stream's previous batch (whose rows are collected first);
+        the batches of the other streams are in flight meanwhile."""
+        s = i % F
+        done = pending[s].result() if pending[s] is not None else None
+        with torch.cuda.stream(lanes[s]):
+            pending[s] = filter_results_async(model(xs[s]), params)
+        return done
+
+    def drain():
+        outs = []
+        for s in range(F):
+            if pending[s] is not None:
+                outs.append(pending[s].result())
+                pending[s] = None
+        return outs
+
     nms_events = []
 
     def step(record):
@@ -280,16 +308,20 @@ def main():
             nms_events.append((e0, e1))
         return out
 
+    for i in range(max(args.warmup, F)):
+        flight_step(i)
+    drain()
     for _ in range(args.warmup):
         out = step(False)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    plan.stage_events = []
+    # ---- the timed region: exactly `steps` passes, F batches in flight
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(True)
+    for i in range(args.steps):
+        flight_step(i)
+    outs = drain()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -299,6 +331,13 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- the same passes one after the other on one stream, with events around the stages
+    plan.stage_events = []
+    ts0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(True)
+    torch.cuda.synchronize()
+    serial_elapsed = time.perf_counter() - ts0
 
     conv_ms = float(np.mean([e[0].elapsed_time(e[2]) for e in plan.stage_events]))
     nms_ms = float(np.mean([a.elapsed_time(b) for a, b in nms_events]))
@@ -315,23 +354,26 @@ def main():
         except Exception as exc:       # the throughput line must not depend on it
             print(f"[bench] gather_detections failed on rank {rank}: {exc}", file=sys.stderr, flush=True)
 
+    if F > 1 and outs:
+        out = outs[-1]
     pipelined = None
     if world == 1 and not args.no_pipelined:
         from yolo_amd.harness import DetectionPipeline
         pipe = DetectionPipeline(model, params)
-        for _ in range(args.warmup):
-            pipe.submit(x)
+        for i in range(args.warmup):
+            pipe.submit(xs[i % F])
         pipe.flush()
         torch.cuda.synchronize()
         tp0 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe.submit(x)
+        for i in range(args.steps):
+            pipe.submit(xs[i % F])
         pipe.flush()
         torch.cuda.synchronize()
         tp = time.perf_counter() - tp0
         pipelined = {"value": round(B * args.steps / tp, 2), "unit": "images/sec",
                      "ms_per_step": round(1e3 * tp / args.steps, 4),
-                     "how": "NMS of batch i on a second HIP stream beside the forward pass of batch i+1"}
+                     "how": "harness.DetectionPipeline: the callers' loop with two batches in flight on two "
+                            "HIP streams, results handed back in order"}
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -394,7 +436,11 @@ def main():
             "config": {"workload": f"YOLOv3-{H} Darknet-53, batch {B} per GPU, conf {args.conf} / "
                                    f"NMS {args.nms}, seeded synthetic weights and images",
                        "global_batch": world * B, "height": H, "boxes_per_image": N,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "batches_in_flight_per_gpu": F},
+            "serial": {"value": round(B * args.steps / serial_elapsed, 2), "unit": "images/sec (this rank)",
+                       "ms_per_step": round(1e3 * serial_elapsed / args.steps, 4),
+                       "how": "the same steps one batch after the other on one stream (what stages_ms, "
+                              "roofline_stack and the per-kernel figures are measured in)"},
             "roofline": roofline,
             "roofline_stack": stack,
             "stages_ms": {"conv_stack": round(conv_ms, 4), "nms": round(nms_ms, 4)},

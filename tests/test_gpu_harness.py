@@ -99,13 +99,12 @@ def test_detection_pipeline_returns_what_the_two_calls_return():
         want.append(out if isinstance(out, int) else out.clone())
     pipe = DetectionPipeline(model, params)
     got = []
-    for x in batches:
+    for j, x in enumerate(batches):
         done = pipe.submit(x)
-        if done is not None:
-            got.append(done if isinstance(done, int) else done.clone())
-    last = pipe.flush()
-    got.append(last if isinstance(last, int) else last.clone())
-    assert pipe.flush() is None
+        assert len(done) == (0 if j < 2 else 1)          # two batches in flight
+        got += [d if isinstance(d, int) else d.clone() for d in done]
+    got += [d if isinstance(d, int) else d.clone() for d in pipe.flush()]
+    assert pipe.flush() == []
     assert len(got) == len(want)
     for g, w in zip(got, want):
         if isinstance(w, int):
@@ -116,9 +115,9 @@ def test_detection_pipeline_returns_what_the_two_calls_return():
 
 def test_detection_pipeline_with_a_partial_last_batch_and_unclone_results():
     """Batches of 3, 3, 2, 3 images (a loader's partial batch in the middle and at the
-    end): the buffers are replaced on every shape change, and the result pending at
-    that moment must still come back.  Results are NOT cloned here: a handed-out view
-    stays valid until the second submit() after the one that returned it."""
+    end): a stream's buffers are replaced on a shape change, and the results in flight at
+    that moment must still come back.  Results are NOT cloned here: every output is a
+    tensor of its own and must still hold its rows after later submits."""
     from gpu_helpers import build_model
     from yolo_amd.harness import DetectionPipeline
     from yolo_amd.utilis import filter_results
@@ -144,6 +143,7 @@ def test_detection_pipeline_with_a_partial_last_batch_and_unclone_results():
             assert not isinstance(g, int), f"batch {i}: detections lost"
             assert torch.equal(g.view(torch.int32), w.view(torch.int32)), f"batch {i}"
 
+    n_out = 0
     for j, x in enumerate(batches):
         done = pipe.submit(x)
         # views returned by the previous submit() are still valid after this one
@@ -151,11 +151,15 @@ def test_detection_pipeline_with_a_partial_last_batch_and_unclone_results():
             check(i, g)
             n_checked += 1
         held = []
-        if done is not None:
-            check(j - 1, done)
-            held.append((j - 1, done))
-    check(len(batches) - 1, pipe.flush())
-    assert n_checked == len(batches) - 2
+        for g in done:
+            check(n_out, g)
+            held.append((n_out, g))
+            n_out += 1
+    for g in pipe.flush():
+        check(n_out, g)
+        n_out += 1
+    assert n_out == len(batches)
+    assert n_checked == len(batches) - 3
 
 
 @pytest.mark.parametrize("train", [False, True])
@@ -176,3 +180,27 @@ def test_get_map_with_hip_detections_matches_the_reference(name, train):
     with contextlib.redirect_stdout(io.StringIO()):
         res = ev.get_map(model, data, train=train, confidence=confs if confs else False)
     check_against_golden(name, res, train)
+
+
+def test_concurrent_streams_are_two_distinct_streams_that_overlap():
+    """harness.concurrent_streams: a pair of streams that do not share a hardware queue
+    (two spin kernels take about as long as one), cached per device."""
+    import time
+    from yolo_amd.harness import concurrent_streams
+    a, b = concurrent_streams(torch.device("cuda", 0))
+    assert a.cuda_stream != b.cuda_stream
+    assert concurrent_streams("cuda:0") == (a, b)
+
+    def wall(streams, spin=2_000_000):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(spin)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    wall([a, b])
+    alone = min(wall([a]) for _ in range(3))
+    both = min(wall([a, b]) for _ in range(3))
+    assert both < 1.6 * alone, (alone, both)

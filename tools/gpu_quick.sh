@@ -7,7 +7,7 @@ timeout -k 10 300 python bench.py --no-cpu-baseline --no-traffic "$@" > gpurun_o
 rc=$?; tail -3 gpurun_out/quick_bench.err; python - <<'PY'
 import json
 r=json.load(open("gpurun_out/quick_bench.json"))
-print({k:r[k] for k in ("value","ms_per_step","stages_ms","nms_us_per_img")}, r.get("pipelined",{}).get("value"))
+print({k:r[k] for k in ("value","ms_per_step","stages_ms","nms_us_per_img")}, "serial", r.get("serial",{}).get("value"), "pipeline class", r.get("pipelined",{}).get("value"))
 for k,v in r.get("conv_kernels",{}).items(): print("  ",k,v)
 PY
 exit $rc
