@@ -9,6 +9,6 @@ rc=$?; tail -3 gpurun_out/r2_bench.err; [ $rc -ne 0 ] && exit $rc
 python - <<'PY'
 import json
 r=json.load(open("gpurun_out/r2_bench.json"))
-print({k:r[k] for k in ("value","ms_per_step","stages_ms","nms_us_per_img")}, r["roofline"]["frac"], r["roofline_stack"]["frac"], r["roofline"]["traffic"], r.get("pipelined",{}).get("value"))
+print({k:r[k] for k in ("value","ms_per_step","stages_ms","nms_us_per_img")}, "serial", r["serial"]["value"], r["roofline"]["frac"], r["roofline_stack"]["frac"], r["roofline"]["traffic"], "pipeline class", r.get("pipelined",{}).get("value"))
 PY
 bash tools/prof_round2.sh round2 > gpurun_out/r2_prof.log 2>&1; tail -12 gpurun_out/r2_prof.log

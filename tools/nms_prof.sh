@@ -2,7 +2,7 @@
 # per-kernel NMS times of the benchmark for the library in $YOLO_AMD_LIB (default: the tree's)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/nmsprof
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/nmsprof -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pipelined --no-traffic --no-kernel-pass > /dev/null 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/nmsprof -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pipelined --no-traffic --no-kernel-pass --in-flight 1 > /dev/null 2>&1
 python - <<PY
 import csv,glob,collections
 rows=collections.defaultdict(lambda:[0,0.0])
