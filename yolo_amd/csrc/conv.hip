@@ -1877,7 +1877,7 @@ static int choose_bn(const yolo_amd_conv_desc& d, long long M) {
     // 13x13 layers).  YOLO_AMD_CONV_BN forces a narrower tile (development knob).
     const long long groups128 = ((M + 127) / 128) * (d.cout_pad / 128);
     int want_bn = env_int("YOLO_AMD_CONV_BN", 0);
-    if (want_bn == 0 && BN == 128 && groups128 < 384) want_bn = 64;
+    if (want_bn == 0 && BN == 128 && groups128 < env_int("YOLO_AMD_CONV_BN128_MIN", 384)) want_bn = 64;
     if ((want_bn == 32 || want_bn == 64) && want_bn < BN && d.cout_pad % want_bn == 0) BN = want_bn;
     return BN;
 }
