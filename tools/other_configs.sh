@@ -1,5 +1,5 @@
 #!/bin/bash
-# The BASELINE configurations other than the benchmark's, for orientation.
+# The other reference configurations (608 batch 32, NMS stress, batch-1 latency cases), for orientation.
 cd "$GRAFT_REPO_ROOT"
 run() {
   timeout -k 10 300 python bench.py --no-cpu-baseline --no-traffic --no-pipelined "$@" > gpurun_out/oc.json 2> gpurun_out/oc.err || { tail -3 gpurun_out/oc.err; exit 1; }
