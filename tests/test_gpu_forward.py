@@ -246,8 +246,9 @@ PATCH_CASES = [
 ]
 
 
-@pytest.mark.parametrize("stg", ["1", "3", "3/256", "9"],
-                         ids=["tap-stages", "row-stages", "row-stages-256ch", "private-weight-rings"])
+@pytest.mark.parametrize("stg", ["1", "3", "3/256", "9", "9/256"],
+                         ids=["tap-stages", "row-stages", "row-stages-256ch", "private-weight-rings",
+                              "private-weight-rings-256ch"])
 @pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: c[0])
 def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     from gpu_helpers import conv_reference, run_conv

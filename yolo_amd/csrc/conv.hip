@@ -21,6 +21,7 @@
 // in flight while the MFMAs of tile t run; one barrier per K-tile.
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 #include "conv_layout.h"
@@ -65,9 +66,30 @@ struct ConvArgs {
 };
 
 
+// One LDS-DMA instruction: 16 bytes per lane from gsrc (per lane) to lds_dst (wave-uniform) +
+// 16 * lane.  Issued as inline assembly rather than through the builtin: once the compiler
+// sees an LDS-DMA instruction it stops trusting the order in which LDS reads return and puts a
+// full `s_waitcnt lgkmcnt(0)` in front of the first use of ANY ds_read result, which serialises
+// "eight fragment reads, then twelve MFMAs" where counted waits let the first MFMAs start
+// after the first reads.  The loads' own completion is tracked by hand anyway (wait_vmcnt).
+#ifndef YOLO_AMD_ASM_DMA
+#define YOLO_AMD_ASM_DMA 1
+#endif
 __device__ __forceinline__ void lds_dma16(const __bf16* gsrc, char* lds_dst) {
+#if YOLO_AMD_ASM_DMA
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+    // (m0 is named as clobbered on purpose -- nothing else in these kernels uses it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :
+                 : "v"(gsrc), "s"(base)
+                 : "memory", "m0");
+#pragma clang diagnostic pop
+#else
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+#endif
 }
 
 // ---------------------------------------------------------------- tile epilogue through LDS
@@ -165,7 +187,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// s_waitcnt vmcnt(n) for a count known only after unrolling (0..8)
+// s_waitcnt vmcnt(n) for a count known only after unrolling (n <= 11; larger counts wait for 11)
 __device__ __forceinline__ void wait_vmcnt_upto(int n) {
     switch (n) {
         case 0: wait_vmcnt<0>(); break;
@@ -176,7 +198,10 @@ __device__ __forceinline__ void wait_vmcnt_upto(int n) {
         case 5: wait_vmcnt<5>(); break;
         case 6: wait_vmcnt<6>(); break;
         case 7: wait_vmcnt<7>(); break;
-        default: wait_vmcnt<8>(); break;
+        case 8: wait_vmcnt<8>(); break;
+        case 9: wait_vmcnt<9>(); break;
+        case 10: wait_vmcnt<10>(); break;
+        default: wait_vmcnt<11>(); break;
     }
 }
 
@@ -694,7 +719,8 @@ __global__ void __launch_bounds__(64 * WAVES)
                                        (TC == 4 || (STG == 9 && RING == 4)) ? 2 : (WAVES == 4 ? 3 : 4))))
 conv3x3_patch_kernel(const Conv3Args a) {
     static_assert(STG == 1 || ((STG == 3 || STG == 9) && WAVES == 8), "row-deep weight stages exist for the eight-wave form");
-    static_assert(TC == 2 || (TC == 4 && WAVES == 8 && STG == 3), "the 256-channel tile exists for eight waves, row-deep stages");
+    static_assert(TC == 2 || (TC == 4 && WAVES == 8 && (STG == 3 || STG == 9)),
+                  "the 256-channel tile exists for eight waves, row-deep stages or private rings");
     // STG = 9: every wave stages the weights of ITS 32 channels itself, into a ring of its own
     // (three taps deep, 2 KiB per tap; the two waves of a channel group each hold a copy), so
     // weights never wait for another wave: counted vmcnt waits only, and the workgroup meets
@@ -723,7 +749,8 @@ conv3x3_patch_kernel(const Conv3Args a) {
     // memory runs under the matrix work instead of after it.
     constexpr bool RPRE = WAVES == 8 && STG == 1 && TH == 13 && TW == 13;
     constexpr int TILE_BYTES = P3_TP * 16 * CT * 2;
-    constexpr int RING_BYTES = PRIV ? WAVES * PRIV_R * 2048 : 2 * STG * WSTAGE;   // two stages of STG taps
+    constexpr int PSLOT = TC * 1024;               // bytes of one tap in a private ring: 16 TC channels x 64 B
+    constexpr int RING_BYTES = PRIV ? WAVES * PRIV_R * PSLOT : 2 * STG * WSTAGE;   // two stages of STG taps
     __shared__ __attribute__((aligned(1024))) char lds_all[RING_BYTES + 2 * P3_PATCH + (RPRE ? TILE_BYTES - P3_PATCH : 0)];
     static_assert(sizeof(lds_all) >= TILE_BYTES, "the epilogue tile reuses this memory");
     char* const wring = lds_all;
@@ -830,8 +857,8 @@ conv3x3_patch_kernel(const Conv3Args a) {
     // last two taps into the ring slots those taps no longer fetch weights for.  Layout of a
     // piece: 16 pixels x 64 B, the 16-byte chunk c of pixel p at position c ^ ((p >> 2) & 3)
     // (conflict-free 8-byte reads).
-    constexpr bool OWN_RES = PRIV && PRIV_R == 3 && 2 * P3_PATCH >= P3_PATCH + WAVES * 2048 && NTP <= 6;
-    char* const myring = wring + w * (PRIV_R * 2048);
+    constexpr bool OWN_RES = PRIV && TC == 2 && PRIV_R == 3 && 2 * P3_PATCH >= P3_PATCH + WAVES * 2048 && NTP <= 6;
+    char* const myring = wring + w * (PRIV_R * PSLOT);
     const bool own_res = OWN_RES && a.res && !a.dst_fp32 && (a.Cout & 7) == 0;
     auto res_at = [&](int tp) -> char* {
         return tp < 2 ? lds + P3_PATCH + w * 2048 + tp * 1024 : myring + ((tp - 2) >> 1) * 2048 + (tp & 1) * 1024;
@@ -851,17 +878,19 @@ conv3x3_patch_kernel(const Conv3Args a) {
         lds_dma16(src, res_at(tp));
     };
     if constexpr (PRIV) {
-        static_assert(!PRIV || (PP <= 3 && TC == 2), "private weight rings: 128-channel workgroups");
-        int woffp[2];
+        static_assert(!PRIV || PP <= 3, "private weight rings: patch pieces per wave and chunk");
+        int woffp[TC];
         {
             const int qw = (lane & 3) ^ chunk_swizzle<32>(lane >> 2);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) woffp[i] = (n0 + cg * 32 + i * 16 + (lane >> 2)) * 32 + qw * 8;
+            for (int i = 0; i < TC; ++i) woffp[i] = (n0 + cg * 16 * TC + i * 16 + (lane >> 2)) * 32 + qw * 8;
         }
         auto issue_wp = [&](int chunk, int tap, int slot) {
             const int delta = tap * wstep_tap + chunk * wstep_chunk;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) lds_dma16(a.wgt + (woffp[i] + delta), myring + slot * 2048 + i * 1024);
+            for (int i = 0; i < TC; ++i) {
+                lds_dma16(a.wgt + (woffp[i] + delta), myring + slot * PSLOT + i * 1024);
+            }
         };
         const int wfragp = slot_of<32>(r, q) * 16;
 #pragma unroll
@@ -884,9 +913,9 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     int n_more = 0, n_last = 0, n_res = 0;
 #pragma unroll
                     for (int u = tap - PRIV_R + 2; u <= tap - 1; ++u) {
-                        n_more += 2 + ((u >= 0 && u < PP) ? 1 : 0);
-                        n_last += (u + PRIV_R - 1 <= 8) ? 2 : 0;
-                        n_res += ((u + PRIV_R - 1 <= 8) ? 2 : 0) + ((u == 0 || u == 7) ? 2 : 0);
+                        n_more += TC + ((u >= 0 && u < PP) ? 1 : 0);
+                        n_last += (u + PRIV_R - 1 <= 8) ? TC : 0;
+                        n_res += ((u + PRIV_R - 1 <= 8) ? TC : 0) + ((u == 0 || u == 7) ? 2 : 0);
                     }
                     wait_vmcnt_upto(more_chunks ? n_more : (own_res ? n_res : n_last));
                 }
@@ -915,10 +944,10 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 const int colb = ((r + kw + TW * kh) & 15) * 16 + kh * 256;
                 int cur = slot0 + tap % PRIV_R;
                 if (cur >= PRIV_R) cur -= PRIV_R;
-                const char* ws = myring + cur * 2048 + wfragp;
-                bf16x8 wf[2];
+                const char* ws = myring + cur * PSLOT + wfragp;
+                bf16x8 wf[TC];
 #pragma unroll
-                for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
+                for (int tc = 0; tc < TC; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
                 bf16x8 xf[6];
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
@@ -927,7 +956,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 for (int tp = 0; tp < 6; ++tp) {
                     if (tp >= ntp) break;
 #pragma unroll
-                    for (int tc = 0; tc < 2; ++tc)
+                    for (int tc = 0; tc < TC; ++tc)
                         acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
                 }
                 __builtin_amdgcn_s_setprio(0);
@@ -2021,7 +2050,7 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
         // measured no faster on 26x26 (55.4 against 56.5 us) and slower on 52x52 and 13x13
         // (66.7 against 61.4, 81 against 61 us), so only YOLO_AMD_CONV3_TC=4 selects them
         // (development knob; the variant stays under test)
-        if (c.waves == 8 && c.stg == 3 && d.cout_pad % 256 == 0 && env_int("YOLO_AMD_CONV3_TC", 2) == 4)
+        if (c.waves == 8 && (c.stg == 3 || c.stg == 9) && d.cout_pad % 256 == 0 && env_int("YOLO_AMD_CONV3_TC", 2) == 4)
             c.bn = 256;
         *out = c;
         return YA_OK;
@@ -2112,6 +2141,8 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 19, 10, 2>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.th == 19)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 1, 2, 19, 10>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.bn == 256 && c.stg == 9)
+            hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 4, 13, 13, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.bn == 256)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3, 4>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.waves == 8 && c.stg == 9 && env_int("YOLO_AMD_CONV3_RING", 3) == 4)
