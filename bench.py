@@ -232,7 +232,7 @@ def main():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra pipelined measurement")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-launch event passes")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight per GPU, each on a HIP stream of its own (1: one batch after the other)")
     args = ap.parse_args()
 
@@ -272,7 +272,7 @@ def main():
     F = max(1, args.in_flight)
     from yolo_amd.harness import concurrent_streams
     # (streams that do not share a hardware queue: two that do would run one after the other)
-    lanes = list(concurrent_streams(device)) if F == 2 else [torch.cuda.Stream(device=device) for _ in range(F)]
+    lanes = list(concurrent_streams(device, F)) if F > 1 else [torch.cuda.Stream(device=device)]
     xs = [x] + [torch.from_numpy(gi.images(1000 + rank * F + s, B, H)).to(device) for s in range(1, F)]
     pending = [None] * F
 

@@ -85,7 +85,8 @@ def test_confidence_sweep_with_one_nms(mode, ties, C):
                 assert_bit_equal(np.sort(got_bc, axis=0), np.sort(ref, axis=0), f"image {b} class {c}")
 
 
-def test_detection_pipeline_returns_what_the_two_calls_return():
+@pytest.mark.parametrize("depth", [2, 3])
+def test_detection_pipeline_returns_what_the_two_calls_return(depth):
     from gpu_helpers import build_model
     from yolo_amd.harness import DetectionPipeline
     from yolo_amd.utilis import filter_results
@@ -97,11 +98,11 @@ def test_detection_pipeline_returns_what_the_two_calls_return():
     for x in batches:
         out = filter_results(model(x), params)
         want.append(out if isinstance(out, int) else out.clone())
-    pipe = DetectionPipeline(model, params)
+    pipe = DetectionPipeline(model, params, depth=depth)
     got = []
     for j, x in enumerate(batches):
         done = pipe.submit(x)
-        assert len(done) == (0 if j < 2 else 1)          # two batches in flight
+        assert len(done) == (0 if j < depth else 1)      # `depth` batches in flight
         got += [d if isinstance(d, int) else d.clone() for d in done]
     got += [d if isinstance(d, int) else d.clone() for d in pipe.flush()]
     assert pipe.flush() == []

@@ -159,14 +159,15 @@ def detections_by_conf(prediction, params, conf_list):
 _STREAM_PAIRS = {}
 
 
-def concurrent_streams(device):
-    """Two HIP streams of `device` whose kernels really run side by side.  The runtime
+def concurrent_streams(device, n=2):
+    """`n` HIP streams of `device` whose kernels really run side by side.  The runtime
     maps streams onto a few hardware queues (four by default), and two streams that land
-    on the same queue run one after the other; which ones do is not exposed, so pairs are
-    tried with a short spin kernel on each until the two overlap (cached per device)."""
+    on the same queue run one after the other; which ones do is not exposed, so candidates
+    are tried with a short spin kernel on each stream until `n` of them overlap (cached per
+    device; if fewer can be found the last candidates tried fill the list)."""
     import time
     device = torch.device(device)
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), int(n))
     if key in _STREAM_PAIRS:
         return _STREAM_PAIRS[key]
     with torch.cuda.device(device):
@@ -181,19 +182,21 @@ def concurrent_streams(device):
             torch.cuda.synchronize()
             return time.perf_counter() - t0
 
-        first = torch.cuda.Stream(device=device)
-        wall([first])
-        alone = min(wall([first]) for _ in range(3))
-        pair = None
-        for _ in range(12):
+        chosen = [torch.cuda.Stream(device=device)]
+        wall(chosen)
+        alone = min(wall(chosen) for _ in range(3))
+        tries = 0
+        while len(chosen) < n and tries < 16:
+            tries += 1
             cand = torch.cuda.Stream(device=device)
-            wall([first, cand])
-            both = min(wall([first, cand]) for _ in range(3))
-            pair = (first, cand)
-            if both < 1.5 * alone:
-                break
-    _STREAM_PAIRS[key] = pair
-    return pair
+            wall(chosen + [cand])
+            together = min(wall(chosen + [cand]) for _ in range(3))
+            if together < 1.5 * alone or tries == 16:
+                chosen.append(cand)
+        while len(chosen) < n:
+            chosen.append(torch.cuda.Stream(device=device))
+    _STREAM_PAIRS[key] = tuple(chosen)
+    return _STREAM_PAIRS[key]
 
 
 class DetectionPipeline:
@@ -218,17 +221,20 @@ class DetectionPipeline:
 
     LANES = 2
 
-    def __init__(self, model, params):
+    def __init__(self, model, params, depth=None):
+        """depth: batches in flight (default 2; a third adds about 2 % more images/s at
+        batch 32 and a batch more of latency)."""
         _lib.require_gpu()
         self.model, self.params = model, params
         self.device = next(model.parameters()).device
-        self.lanes = list(concurrent_streams(self.device))
+        self.LANES = int(depth) if depth else DetectionPipeline.LANES
+        self.lanes = list(concurrent_streams(self.device, self.LANES))
         self._n = 0
         self._pending = []              # PendingDetections of the batches in flight, oldest first
 
     def submit(self, images):
         """Queue forward + NMS for `images`.  Returns the list of outputs that this call
-        retires: empty while fewer than two batches are in flight, else the output of the
+        retires: empty while fewer than `depth` batches are in flight, else the output of the
         oldest one (whose stream this batch is queued behind)."""
         from .utilis import filter_results_async
         main = torch.cuda.current_stream(self.device)
