@@ -63,7 +63,7 @@ def oracle_forward(sd, H, C, A, x_np, return_layers=False):
 
 
 def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None, fp32_out=False,
-             splitk=False, info=None, bn=None):
+             splitk=False, info=None, bn=None, repeat=1):
     """One fused layer through yolo_amd_conv_forward.  splitk: lend the scratch the
     library asks for, so a layer with few output tiles splits its reduction; info (a
     dict) receives "splitk_bytes" and "choice" (the kernel the library picks, as
@@ -74,6 +74,8 @@ def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None
     bn: dict(gamma, beta, running_mean, running_var, num_batches_tracked, eps, momentum) of
     CUDA tensors / floats: BatchNorm2d on batch statistics behind the convolution (w then
     holds the convolution's own weights); the running tensors are updated in place.
+    repeat > 1: the same descriptor (and scratch) is launched again that many times; every
+    launch must write the same bits.
     Returns the NHWC output tensor (bf16, or fp32 when fp32_out)."""
     from yolo_amd import _lib
     from yolo_amd._lib import ConvDesc, lib, check
@@ -127,6 +129,13 @@ def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None
         info["choice"] = _lib.conv_choice(d[0])      # which kernel the library runs for this layer
     check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), _lib.current_stream_ptr(dev)), "conv")
     torch.cuda.synchronize()
+    for _ in range(repeat - 1):
+        assert bn is None, "a train-mode layer moves its running statistics on every launch"
+        first = out.clone()
+        out.fill_(float("nan"))
+        check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), _lib.current_stream_ptr(dev)), "conv")
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.uint8), first.view(torch.uint8)), "a second launch wrote different bits"
     return out
 
 

@@ -83,8 +83,10 @@ def test_conv_query_reports_the_kernel_without_a_gpu():
     assert q(desc(32, 40, 256, 512, 3, 1))["kernel"] == "igemm"          # 320: no tile shape for 10 * 2^n maps
     c = q(desc(32, 52, 256, 128, 1, 1))
     assert (c["kernel"], c["bn"], c["bk"], c["act_ksteps"], c["lds_stages"]) == ("igemm", 128, 32, 2, 2)
-    c = q(desc(1, 52, 256, 128, 1, 1))
+    c = q(desc(4, 52, 256, 128, 1, 1))
     assert (c["kernel"], c["bn"]) == ("igemm", 64)                      # few tiles: narrower channel tile
+    c = q(desc(1, 52, 256, 128, 1, 1))
+    assert (c["kernel"], c["bn"]) == ("igemm", 32)                      # a single image: narrower still
     c = q(desc(32, 13, 1024, 512, 1, 1))
     assert (c["kernel"], c["bn"], c["bk"], c["act_ksteps"]) == ("igemm", 64, 64, 1)
     bad = desc(1, 13, 48, 64, 5, 1)

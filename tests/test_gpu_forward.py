@@ -518,8 +518,9 @@ def test_split_reduction_matches_the_reference_and_the_single_pass(case):
         res = torch.from_numpy(r.standard_normal((B, Ho, Ho, cout)).astype(np.float32)).cuda().to(torch.bfloat16)
     info = {}
     split = run_conv(x0, w, bias, stride=stride, leaky=leaky, residual=res, fp32_out=fp32_out, splitk=True,
-                     info=info).float().cpu()
+                     info=info, repeat=3).float().cpu()
     assert info["splitk_bytes"] > 0, "this shape was meant to be split"
+    assert info["choice"]["k_slices"] > 1
     single = run_conv(x0, w, bias, stride=stride, leaky=leaky, residual=res, fp32_out=fp32_out).float().cpu()
     want = conv_reference(x0, w, bias, stride=stride, leaky=leaky, residual=res)
     assert torch.isfinite(split).all(), "output holds NaN/inf (unwritten elements or scratch read before written)"

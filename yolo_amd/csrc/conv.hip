@@ -1828,23 +1828,6 @@ conv_splitk_finish_kernel(const FinishArgs a) {
     else reinterpret_cast<__bf16*>(a.dst)[e] = (__bf16)x;
 }
 
-// K-steps per slice and number of slices for a layer of `wgs` output tiles and KT
-// K-steps (of 32), or slices = 1: split only when the tiles alone leave most CUs
-// idle and the reduction is long enough to pay for the second launch (measured at
-// batch 1: a K-step costs a lone workgroup about 0.3 us, the finishing launch 7-8 us;
-// 3x3 layers on >= 256 channels gain 8-24 us each, 36-step layers and every 1x1 layer
-// lose), keep at least four steps per slice, an even number of them (the two-step
-// activation tile), and no more slices than fill the chip about twice.
-static void splitk_plan(long long wgs, int KT, int* steps, int* slices) {
-    *steps = KT; *slices = 1;
-    if (wgs > 128 || KT < 64) return;
-    int want = (int)std::min<long long>(16, std::max<long long>(1, 512 / wgs));
-    int len = (KT + want - 1) / want;
-    len = std::max(4, (len + 1) & ~1);
-    const int n = (KT + len - 1) / len;
-    if (n >= 2) { *steps = len; *slices = n; }
-}
-
 template <int BM, int BN, int BK, int WAVES_M, int NSTAGE, int AMUL = 1>
 static void launch_igemm(ConvArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
@@ -1898,6 +1881,24 @@ static void* env_ptr(const char* name) {
 }
 #endif
 
+// K-steps per slice and number of slices for a layer of `wgs` output tiles and KT
+// K-steps (of 32), or slices = 1: split only when the tiles alone leave most CUs
+// idle and the reduction is long enough to pay for the second launch (measured at
+// batch 1: a K-step costs a lone workgroup about 0.3 us, the finishing launch 7-8 us;
+// 3x3 layers on >= 256 channels gain 8-24 us each, 36-step layers and every 1x1 layer
+// lose), keep at least four steps per slice, an even number of them (the two-step
+// activation tile), and no more slices than fill the chip about twice.
+static void splitk_plan(long long wgs, int KT, int* steps, int* slices) {
+    *steps = KT; *slices = 1;
+    // (YOLO_AMD_SPLITK_MAX_WGS / _MIN_KT / _FILL: development knobs for these three numbers)
+    if (wgs > env_int("YOLO_AMD_SPLITK_MAX_WGS", 128) || KT < env_int("YOLO_AMD_SPLITK_MIN_KT", 64)) return;
+    int want = (int)std::min<long long>(16, std::max<long long>(1, env_int("YOLO_AMD_SPLITK_FILL", 512) / wgs));
+    int len = (KT + want - 1) / want;
+    len = std::max(4, (len + 1) & ~1);
+    const int n = (KT + len - 1) / len;
+    if (n >= 2) { *steps = len; *slices = n; }
+}
+
 // Channel tile of the im2col kernel for a layer with M output pixels.
 static int choose_bn(const yolo_amd_conv_desc& d, long long M) {
     int BN = pick_bn(d.cout);
@@ -1907,6 +1908,14 @@ static int choose_bn(const yolo_amd_conv_desc& d, long long M) {
     const long long groups128 = ((M + 127) / 128) * (d.cout_pad / 128);
     int want_bn = env_int("YOLO_AMD_CONV_BN", 0);
     if (want_bn == 0 && BN == 128 && groups128 < env_int("YOLO_AMD_CONV_BN128_MIN", 384)) want_bn = 64;
+    // One or two images: even 64-channel tiles leave most CUs idle, and a lone workgroup's
+    // K loop is bound by the bytes it pulls through its own CU, so 32-channel tiles (twice
+    // the workgroups, each loading less) shorten it: 7-9 % on the batch-1 forward pass,
+    // neutral from batch 2 on at this threshold, 3-9 % slower at batch 2-4 with 128 or more
+    // (YOLO_AMD_CONV_BN64_MIN moves it, counted in 128 x 64 tiles).
+    if ((want_bn == 0 || want_bn == 64) && BN >= 64 && env_int("YOLO_AMD_CONV_BN", 0) == 0 &&
+        ((M + 127) / 128) * (d.cout_pad / 64) < env_int("YOLO_AMD_CONV_BN64_MIN", 64))
+        want_bn = 32;
     if ((want_bn == 32 || want_bn == 64) && want_bn < BN && d.cout_pad % want_bn == 0) BN = want_bn;
     return BN;
 }
