@@ -30,6 +30,34 @@ __global__ void __launch_bounds__(256) mfma_loop(const __bf16* src, float* dst, 
     if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// the same with v_mfma_f32_32x32x16_bf16 (twice the work per instruction, 32 cycles each)
+template <int NACC>
+__global__ void __launch_bounds__(256) mfma32_loop(const __bf16* src, float* dst, int iters, long long* clocks) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a = *reinterpret_cast<const bf16x8*>(src + lane * 8);
+    bf16x8 b = *reinterpret_cast<const bf16x8*>(src + 512 + lane * 8);
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += acc[i][j];
+    dst[(size_t)blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clocks[0] = c1 - c0; clocks[1] = w1 - w0; }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
 int main() {
@@ -63,6 +91,29 @@ int main() {
             printf("%s operands, %d waves per SIMD: %.2f ms, %.0f TFLOP/s, %.2f GHz if an MFMA takes 16 cycles; "
                    "clock64 %lld, wall_clock64 %lld (100 MHz)\n", zero ? "zero" : "random", wgs_per_cu, ms,
                    flop / (ms * 1e-3) / 1e12, mfma_per_simd * 16 / (ms * 1e-3) / 1e9, hc[0], hc[1]);
+        }
+    }
+    {
+        std::vector<__bf16> h(1024);
+        srand(1);
+        for (auto& v : h) v = (__bf16)((rand() % 2001 - 1000) / 1000.f);
+        CK(hipMemcpy(src, h.data(), 1024 * sizeof(__bf16), hipMemcpyHostToDevice));
+        for (int wgs_per_cu = 1; wgs_per_cu <= 2; wgs_per_cu *= 2) {
+            const int grid = 256 * wgs_per_cu, it32 = iters;
+            hipLaunchKernelGGL(mfma32_loop<3>, dim3(grid), dim3(256), 0, 0, src, dst, 200, clocks);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(mfma32_loop<3>, dim3(grid), dim3(256), 0, 0, src, dst, it32, clocks);
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            float ms = 0.f;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            long long hc[2];
+            CK(hipMemcpy(hc, clocks, sizeof(hc), hipMemcpyDeviceToHost));
+            const double flop = (double)grid * 4 * it32 * 3 * 32768.0;
+            printf("32x32x16, random operands, %d waves per SIMD: %.2f ms, %.0f TFLOP/s; clock64 %lld, wall_clock64 %lld; "
+                   "%.1f cycles per MFMA per SIMD\n", wgs_per_cu, ms, flop / (ms * 1e-3) / 1e12, hc[0], hc[1],
+                   (double)hc[0] / ((double)wgs_per_cu * it32 * 3));
         }
     }
     return 0;

@@ -92,6 +92,25 @@ __device__ __forceinline__ void lds_dma16(const __bf16* gsrc, char* lds_dst) {
 #endif
 }
 
+// The same with the address split into a wave-uniform base (a scalar register pair) and a
+// 32-bit per-lane byte offset, plus OFF constant bytes (the instruction's offset field, which the
+// hardware adds to the source address AND to the LDS address): the form for a source whose per-lane part
+// never changes (weights: one offset register for the whole kernel, the walk over taps and
+// channel chunks done in scalar arithmetic, no vector instruction per load -- the vector
+// instructions of the tap loop compete with the MFMAs of the other waves for issue slots).
+template <int OFF = 0>
+__device__ __forceinline__ void lds_dma16_sv(const __bf16* sbase, uint32_t lane_bytes, char* lds_dst) {
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed instruction offset");
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 :
+                 : "v"(lane_bytes), "s"(sbase), "s"(base), "n"(OFF)
+                 : "memory", "m0");
+#pragma clang diagnostic pop
+}
+
 // ---------------------------------------------------------------- tile epilogue through LDS
 // The accumulator layout (one pixel x 4 channels per lane) gives 8-byte stores
 // scattered over 16 rows, and a residual that is loaded just before it is
@@ -324,6 +343,9 @@ conv_igemm_kernel(const ConvArgs a) {
             woff[i] = ((kw >> 5) * cout_pad + n0 + row) * 32 + (kw & 31);
         }
     }
+    uint32_t woffb[NB];                         // the same in bytes: the weight loads' per-lane part
+#pragma unroll
+    for (int i = 0; i < NB; ++i) woffb[i] = (uint32_t)woff[i] * 2u;
 
     // ---- K-steps of this workgroup: all of them, or one slice of a split reduction
     int kt0 = 0, kt1 = a.Kpad / BK;
@@ -347,11 +369,23 @@ conv_igemm_kernel(const ConvArgs a) {
     const __bf16* act_base = nullptr;
     int act_delta = 0, act_tap = 0;
     bool act_second = false;
+    // 1x1 layers have no border taps: a lane's byte offset into its source never changes, so the
+    // walk over the channels is scalar arithmetic and the loads take the scalar-base form (rows
+    // beyond M read pixel 0; their outputs are never stored)
+    const bool flat = a.ksize == 1;
+    uint32_t offb0[NA], offb1[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        offb0[i] = (uint32_t)(off0[i] + koff) * 2u;
+        offb1[i] = (uint32_t)(off1[i] + koff) * 2u;
+    }
+    const __bf16* act_sbase = nullptr;
     auto act_begin = [&]() {
         act_second = k_c >= a.C0;
         act_base = act_second ? a.src1 : a.src0;
         const int Csrc = act_second ? a.C1 : a.C0;
         const int Wsrc = act_second ? a.W : W0;
+        act_sbase = act_base + (act_second ? k_c - a.C0 : k_c);
         act_delta = ((k_kh - pad) * Wsrc + (k_kw - pad)) * Csrc + (act_second ? k_c - a.C0 : k_c) + koff;
         act_tap = k_tap;
         k_c += BKA;
@@ -364,10 +398,14 @@ conv_igemm_kernel(const ConvArgs a) {
     auto act_one = [&](char* sA, int i) {
         const int j = i * 4 + w;
         if ((TA % 4 == 0) || j < TA) {
-            const bool v = (vmask[i] >> act_tap) & 1;
-            const int eo = (act_second ? off1[i] : off0[i]) + act_delta;
-            const __bf16* p = v ? (act_base + eo) : a.zero;
-            lds_dma16(p, sA + j * 1024);
+            if (flat) {
+                lds_dma16_sv<0>(act_sbase, act_second ? offb1[i] : offb0[i], sA + j * 1024);
+            } else {
+                const bool v = (vmask[i] >> act_tap) & 1;
+                const int eo = (act_second ? off1[i] : off0[i]) + act_delta;
+                const __bf16* p = v ? (act_base + eo) : a.zero;
+                lds_dma16(p, sA + j * 1024);
+            }
         }
     };
     auto stage_act = [&](char* sA) {
@@ -379,7 +417,7 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int j = i * 4 + w;
-            if ((TB % 4 == 0) || j < TB) lds_dma16(a.wgt + (woff[i] + kt * (BK * cout_pad)), sB + j * 1024);
+            if ((TB % 4 == 0) || j < TB) lds_dma16_sv<0>(a.wgt + kt * (BK * cout_pad), woffb[i], sB + j * 1024);
         }
     };
     auto stage = [&](int buf, int kt) {
@@ -879,17 +917,19 @@ conv3x3_patch_kernel(const Conv3Args a) {
     };
     if constexpr (PRIV) {
         static_assert(!PRIV || PP <= 3, "private weight rings: patch pieces per wave and chunk");
-        int woffp[TC];
-        {
-            const int qw = (lane & 3) ^ chunk_swizzle<32>(lane >> 2);
-#pragma unroll
-            for (int i = 0; i < TC; ++i) woffp[i] = (n0 + cg * 16 * TC + i * 16 + (lane >> 2)) * 32 + qw * 8;
-        }
+        // this lane's 16 bytes inside a 16-channel piece (1 KiB, [channel][32] with swizzled chunks);
+        // the piece's own address is wave-uniform
+        const uint32_t wlane = (uint32_t)(((lane >> 2) * 32 + ((lane & 3) ^ chunk_swizzle<32>(lane >> 2)) * 8) * 2);
+        const int wbase = (n0 + cg * 16 * TC) * 32;
         auto issue_wp = [&](int chunk, int tap, int slot) {
-            const int delta = tap * wstep_tap + chunk * wstep_chunk;
-#pragma unroll
-            for (int i = 0; i < TC; ++i) {
-                lds_dma16(a.wgt + (woffp[i] + delta), myring + slot * PSLOT + i * 1024);
+            const __bf16* const sb = a.wgt + (wbase + tap * wstep_tap + chunk * wstep_chunk);
+            char* const dst = myring + slot * PSLOT;
+            static_assert(TC == 2 || TC == 4, "pieces per tap");
+            lds_dma16_sv<0>(sb, wlane, dst);               // piece i: 1 KiB further in memory and in the slot
+            lds_dma16_sv<1024>(sb, wlane, dst);
+            if constexpr (TC == 4) {
+                lds_dma16_sv<2048>(sb, wlane, dst);
+                lds_dma16_sv<3072>(sb, wlane, dst);
             }
         };
         const int wfragp = slot_of<32>(r, q) * 16;
@@ -952,6 +992,32 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
                 __builtin_amdgcn_s_setprio(2);
+#ifdef YOLO_AMD_MFMA32_TIMING
+                // TIMING EXPERIMENT ONLY (wrong arithmetic): the same registers, LDS reads and matrix-pipe
+                // cycles with six 32x32x16 instructions in place of twelve 16x16x32
+                if constexpr (TC == 2) {
+                    typedef float f32x16 __attribute__((ext_vector_type(16)));
+                    f32x16 c32[3];
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        const f32x4 p0 = acc[0][2 * b], p1 = acc[1][2 * b], p2 = acc[0][2 * b + 1], p3 = acc[1][2 * b + 1];
+                        c32[b] = f32x16{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3],
+                                        p2[0], p2[1], p2[2], p2[3], p3[0], p3[1], p3[2], p3[3]};
+                    }
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) c32[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[2 * b], c32[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) c32[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[2 * b + 1], c32[b], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            acc[0][2 * b][i] = c32[b][i]; acc[1][2 * b][i] = c32[b][4 + i];
+                            acc[0][2 * b + 1][i] = c32[b][8 + i]; acc[1][2 * b + 1][i] = c32[b][12 + i];
+                        }
+                    }
+                } else
+#endif
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) {
                     if (tp >= ntp) break;
