@@ -992,32 +992,6 @@ conv3x3_patch_kernel(const Conv3Args a) {
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
                 __builtin_amdgcn_s_setprio(2);
-#ifdef YOLO_AMD_MFMA32_TIMING
-                // TIMING EXPERIMENT ONLY (wrong arithmetic): the same registers, LDS reads and matrix-pipe
-                // cycles with six 32x32x16 instructions in place of twelve 16x16x32
-                if constexpr (TC == 2) {
-                    typedef float f32x16 __attribute__((ext_vector_type(16)));
-                    f32x16 c32[3];
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-                        const f32x4 p0 = acc[0][2 * b], p1 = acc[1][2 * b], p2 = acc[0][2 * b + 1], p3 = acc[1][2 * b + 1];
-                        c32[b] = f32x16{p0[0], p0[1], p0[2], p0[3], p1[0], p1[1], p1[2], p1[3],
-                                        p2[0], p2[1], p2[2], p2[3], p3[0], p3[1], p3[2], p3[3]};
-                    }
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) c32[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[2 * b], c32[b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) c32[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[2 * b + 1], c32[b], 0, 0, 0);
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            acc[0][2 * b][i] = c32[b][i]; acc[1][2 * b][i] = c32[b][4 + i];
-                            acc[0][2 * b + 1][i] = c32[b][8 + i]; acc[1][2 * b + 1][i] = c32[b][12 + i];
-                        }
-                    }
-                } else
-#endif
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) {
                     if (tp >= ntp) break;
