@@ -322,13 +322,11 @@ conv_igemm_kernel(const ConvArgs a) {
                 if (a.ksize == 1) {
                     vbits = 1;
                 } else {
-#pragma unroll
-                    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                        for (int kw = 0; kw < 3; ++kw) {
-                            const int iy = iyc + kh - 1, ix = ixc + kw - 1;
-                            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) vbits |= 1 << (kh * 3 + kw);
-                        }
+                    // bit kh*3 + kw: input row iyc + kh - 1 and column ixc + kw - 1 exist.  The centre
+                    // always does; the column bits times the row bits spread to 0, 3, 6 gives all nine.
+                    const int cm = (ixc > 0 ? 1 : 0) | 2 | (ixc + 1 < a.W ? 4 : 0);
+                    const int rm = (iyc > 0 ? 1 : 0) | 8 | (iyc + 1 < a.H ? 64 : 0);
+                    vbits = cm * rm;
                 }
             }
             vmask[i] = vbits;
