@@ -30,9 +30,10 @@ __global__ void __launch_bounds__(512) rate_kernel(const char* src, uint32_t* si
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
         if (MODE != 0) {
+            asm volatile("" ::: "memory");                 // LDS may have changed: read again
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + w * 4096 + ((k & 3) * 1024) + lane * 16);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(lds + w * 4096 + ((k * 384 + lane * 16) & 4095));
                 acc += v;
             }
         }
