@@ -1487,7 +1487,7 @@ __global__ void __launch_bounds__(256)
 conv_stem_kernel(const StemArgs a) {
     constexpr int PLANE_IN = STEM_IR * STEM_IC;
     __shared__ __attribute__((aligned(1024))) char lds[STEM_IN_BYTES + STEM_L0_BYTES];
-    float* const inpatch = reinterpret_cast<float*>(lds);
+    uint32_t* const inwords = reinterpret_cast<uint32_t*>(lds);   // input patch: bf16 hi << 16 | bf16 lo per value
     char* const l0 = lds + STEM_IN_BYTES;                  // first-layer patch; later the output tile
     static_assert(STEM_TY * STEM_TX * 64 * 2 <= STEM_L0_BYTES, "output tile fits where the patch was");
     static_assert(STEM_STRIPS % 4 == 0, "strips split evenly over the four waves");
@@ -1572,7 +1572,15 @@ conv_stem_kernel(const StemArgs a) {
         __syncthreads();                                   // the previous tile's output tile has been stored
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-            if ((int)threadIdx.x + 256 * u < total) inpatch[threadIdx.x + 256 * u] = __uint_as_float(stage[u]);
+            if ((int)threadIdx.x + 256 * u < total) {
+                // split once here into bf16 hi and lo halves of one word (every input value is
+                // gathered by up to nine taps below, which used to split it nine times)
+                const float t = __uint_as_float(stage[u]);
+                const __bf16 h = (__bf16)t;
+                const __bf16 l = (__bf16)(t - (float)h);
+                inwords[threadIdx.x + 256 * u] = ((uint32_t)__builtin_bit_cast(unsigned short, h) << 16) |
+                                                 (uint32_t)__builtin_bit_cast(unsigned short, l);
+            }
         __syncthreads();
         fetch(min(tile + step, last));                     // next tile streams in meanwhile
 
@@ -1582,14 +1590,17 @@ conv_stem_kernel(const StemArgs a) {
             const int p = (w + 4 * i) * 16 + n;
             const int pp = min(p, STEM_NPIX - 1);
             const int pr = pp / STEM_PC, pc = pp - pr * STEM_PC;
-            const float* ip = inpatch + pr * STEM_IC + pc;
-            bf16x8 xf, xl;
+            const uint32_t* ip = inwords + pr * STEM_IC + pc;
+            uint32_t wv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float t = ip[offl[j]];
-                xf[j] = (__bf16)t;
-                xl[j] = (__bf16)(t - (float)xf[j]);
+            for (int j = 0; j < 8; ++j) wv[j] = ip[offl[j]];
+            u32x4 xfw, xlw;                                // element j: half (j & 1) of word j / 2
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                xfw[k] = __builtin_amdgcn_perm(wv[2 * k + 1], wv[2 * k], 0x07060302u);   // the two hi halves
+                xlw[k] = __builtin_amdgcn_perm(wv[2 * k + 1], wv[2 * k], 0x05040100u);   // the two lo halves
             }
+            const bf16x8 xf = __builtin_bit_cast(bf16x8, xfw), xl = __builtin_bit_cast(bf16x8, xlw);
             f32x4 acc0[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
