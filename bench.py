@@ -14,6 +14,11 @@ max-over-ranks of the elapsed time.  (yolo_amd.dist.gather_detections, the one
 exchange a caller such as an mAP evaluation needs afterwards, is exercised once
 after the timed region.)
 
+Started without a launcher (WORLD_SIZE unset) and with --gpus N > 1, this script launches
+itself: before anything touches the GPU it starts `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a child process, relays the child's output and exits
+with its status (--spawn forces that route for N = 1 as well).
+
 Rank 0 prints ONE JSON line.  Beside the required fields it carries
   roofline      the dominant kernel (the patch-reuse 3x3 convolution, half of the
                 step's GPU time) against the dense bf16 MFMA peak: algorithmic FLOPs
@@ -24,6 +29,9 @@ Rank 0 prints ONE JSON line.  Beside the required fields it carries
                 child processes before this process touches the GPU (N = 1 only)
   roofline_stack the whole conv stack (74 launches) the same way, its time taken
                 from HIP events inside the timed steps
+  roofline_composite  the per-layer bound: sum over the conv layers of
+                max(FLOPs / MFMA peak, algorithmic bytes / HBM peak), the images/s it
+                allows, and the achieved fraction of it (whole step and conv stack alone)
   conv_kernels  per kernel family: launches, time, TFLOP/s (same event passes)
   cpu_baseline  the CPU port of the same path (torch CPU fp32 forward + the
                 reference-shaped Python-loop NMS) on a bounded sample, rank 0,
@@ -78,9 +86,12 @@ def build_model(H, C, A, device, conf, nms):
     return model, params, sd, blocks
 
 
-def cpu_baseline(sd, H, C, A, conf, nms, budget_s=20.0, max_images=4):
-    """CPU port of the path on the host cores: stock torch CPU ops for the
-    forward, the reference-shaped per-box Python loop for NMS."""
+def cpu_baseline(sd, H, C, A, conf, nms, budget_s=24.0):
+    """CPU port of the path on the host cores: stock torch CPU ops for the forward, the
+    reference-shaped per-box Python loop for NMS, all host threads this job owns.  Batch 1
+    (3 warm-up + up to 10 timed passes) and batch 32 (the GPU workload's batch; one pass
+    takes seconds, so 1 warm-up + as many timed passes as the budget allows, at least 2):
+    median and minimum wall-clock per pass."""
     import gen_inputs as gi
     import yolo_oracle as orc
     from yolo_amd.cfg import default_params, yolov3_cfg_text
@@ -90,25 +101,78 @@ def cpu_baseline(sd, H, C, A, conf, nms, budget_s=20.0, max_images=4):
     torch.set_num_threads(threads)
     blocks = orc.parse_cfg_text(yolov3_cfg_text(C, A))
     p = default_params(H, C, A)
-    x = torch.from_numpy(gi.images(0, 1, H))
-    orc.forward(sd, blocks, p, x)                 # warm-up (thread pool, allocator)
-    t_fwd = t_nms = 0.0
-    done = 0
-    t0 = time.perf_counter()
-    while done < max_images and (time.perf_counter() - t0) < budget_s:
-        x = torch.from_numpy(gi.images(100 + done, 1, H))
+
+    def one_pass(x):
         a = time.perf_counter()
         det = orc.forward(sd, blocks, p, x)
         b = time.perf_counter()
         orc.filter_results_torch_loop(det, conf, nms, C)
         c = time.perf_counter()
-        t_fwd += b - a
-        t_nms += c - b
-        done += 1
-    total = t_fwd + t_nms
-    return {"value": done / total, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"{done} images at {H}x{H}, batch 1, conf {conf} / NMS {nms}; "
-                      f"forward {1e3 * t_fwd / done:.0f} ms/img, NMS {1e3 * t_nms / done:.0f} ms/img"}
+        return b - a, c - b
+
+    def run(batch, warm, max_timed, min_timed, budget):
+        t0 = time.perf_counter()
+        xs = [torch.from_numpy(gi.images(100 + 7 * batch + i, batch, H)) for i in range(2)]
+        for i in range(warm):
+            one_pass(xs[i % 2])
+        fwd, nm = [], []
+        while len(fwd) < max_timed and (len(fwd) < min_timed or time.perf_counter() - t0 < budget):
+            f, n = one_pass(xs[len(fwd) % 2])
+            fwd.append(f)
+            nm.append(n)
+        tot = np.asarray(fwd) + np.asarray(nm)
+        return {"batch": batch, "warmup": warm, "timed": len(fwd),
+                "images_per_sec_median": round(batch / float(np.median(tot)), 3),
+                "images_per_sec_best": round(batch / float(tot.min()), 3),
+                "ms_per_pass_median": round(1e3 * float(np.median(tot)), 1),
+                "ms_per_pass_min": round(1e3 * float(tot.min()), 1),
+                "forward_ms_per_img_median": round(1e3 * float(np.median(fwd)) / batch, 1),
+                "nms_ms_per_img_median": round(1e3 * float(np.median(nm)) / batch, 1)}
+
+    b1 = run(1, 3, 10, 3, budget_s * 0.25)
+    b32 = run(32, 1, 10, 2, budget_s * 0.75)
+    return {"value": b32["images_per_sec_median"], "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"{H}x{H}, conf {conf} / NMS {nms}: batch 32 ({b32['warmup']} warm-up + {b32['timed']} timed "
+                      f"passes, median) and batch 1 ({b1['warmup']} + {b1['timed']}); value = batch 32 median",
+            "batch32": b32, "batch1": b1}
+
+
+def composite_roofline(ops, B):
+    """Per conv LAYER: algorithmic FLOPs and HBM bytes (every layer reads its input once --
+    the fp32 image for the first, bf16 after, an upsampled source at its own size --, its
+    residual operand once, its weights once per batch, and writes its output once, bf16 or
+    the fp32 prediction rows), and max(FLOPs / MFMA peak, bytes / HBM peak) seconds."""
+    rows = []
+    for op in ops:
+        e = op["ent"]
+        fl = 2.0 * B * op["Ho"] * op["Wo"] * e["cout"] * e["cin"] * e["k"] ** 2
+        inb = sum(B * (op["H"] >> up) * (op["W"] >> up) * c * (4 if op["first"] else 2) for _, c, up in op["src"])
+        outb = B * op["Ho"] * op["Wo"] * e["cout"] * (4 if op["fp32"] else 2)
+        by = inb + outb + (outb if op["res"] else 0) + e["cout"] * e["cin"] * e["k"] ** 2 * 2
+        t_m, t_h = fl / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)
+        rows.append({"index": op["index"], "k": e["k"], "stride": e["stride"], "cin": e["cin"], "cout": e["cout"],
+                     "Ho": op["Ho"], "flops": fl, "bytes": float(by), "t_mfma": t_m, "t_hbm": t_h,
+                     "bound": "mfma" if t_m >= t_h else "hbm", "t_bound": max(t_m, t_h)})
+    return rows
+
+
+def self_launch(args, argv):
+    """No launcher started this process and more than one GPU is asked for (or --spawn):
+    become the launcher.  Nothing here touches the GPU; the ranks are fresh processes."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    child_args = [a for a in argv if a != "--spawn"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *child_args]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] no launcher in the environment: starting {args.gpus} rank(s) with torch.distributed.run",
+          file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
 
 def measure_traffic(argv_tail, steps=3, warmup=1, timeout_s=240):
@@ -199,6 +263,7 @@ def kernel_pass(plan, passes):
     size = ctypes.sizeof(_lib.ConvDesc)
     base = ctypes.addressof(plan.descs)
     acc = {}
+    per_launch = [{"first_op": j0, "n_ops": n, "family": fam, "flops": fl, "ms": 0.0} for j0, n, fam, fl in groups]
     for _ in range(passes):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(groups) + 1)]
         evs[0].record()
@@ -210,13 +275,48 @@ def kernel_pass(plan, passes):
         for g, (j0, n, fam, fl) in enumerate(groups):
             a = acc.setdefault(fam, {"launches": 0, "ms": 0.0, "flops": 0.0})
             a["launches"] += 1
-            a["ms"] += evs[g].elapsed_time(evs[g + 1])
+            dt = evs[g].elapsed_time(evs[g + 1])
+            a["ms"] += dt
             a["flops"] += fl
+            per_launch[g]["ms"] += dt / passes
     for a in acc.values():
         a["launches"] //= passes
         a["ms"] /= passes
         a["flops"] /= passes
-    return acc
+    return acc, per_launch
+
+
+def write_layer_table(path, plan, layers, per_launch, scale, B, H):
+    """One row per conv launch: what ran, its time (HIP events on the launch stream, scaled
+    like conv_kernels), algorithmic FLOPs and bytes, the bound that applies and the fraction
+    of it that was reached."""
+    by_index = {op["index"]: r for op, r in zip(plan.ops, layers)}
+    lines = [f"# per-launch roofline, YOLOv3-{H}, batch {B}: time from HIP events around every conv launch "
+             f"(scaled by {scale:.3f} to the stack's time inside the timed steps)",
+             f"# bound = max(FLOP / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s); frac = bound time / measured time",
+             f"{'block':>5s} {'k':>1s} {'s':>1s} {'cin':>5s} {'cout':>5s} {'map':>4s} {'kernel':44s} {'us':>7s} "
+             f"{'GFLOP':>7s} {'MB':>7s} {'TFLOP/s':>8s} {'GB/s':>7s} {'bound':>5s} {'bound us':>8s} {'frac':>5s}"]
+    tot_us = tot_bound = 0.0
+    for g in per_launch:
+        ops = plan.ops[g["first_op"]:g["first_op"] + g["n_ops"]]
+        rows = [by_index[o["index"]] for o in ops]
+        fl, by = sum(r["flops"] for r in rows), sum(r["bytes"] for r in rows)
+        if g["n_ops"] == 2:       # the fused stem: the first layer's output never goes to memory
+            inter = B * ops[0]["Ho"] * ops[0]["Wo"] * ops[0]["ent"]["cout"] * 2
+            by -= 2 * inter
+        tb = max(fl / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9))
+        bound = "mfma" if fl / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12) >= by / (HBM_PEAK_GBS * 1e9) else "hbm"
+        us = g["ms"] * scale * 1e3
+        last = rows[-1]
+        blk = "+".join(str(o["index"]) for o in ops)
+        lines.append(f"{blk:>5s} {last['k']:1d} {last['stride']:1d} {last['cin']:5d} {last['cout']:5d} {last['Ho']:4d} "
+                     f"{g['family'][:44]:44s} {us:7.1f} {fl / 1e9:7.2f} {by / 1e6:7.1f} {fl / us / 1e6:8.0f} "
+                     f"{by / us / 1e3:7.0f} {bound:>5s} {tb * 1e6:8.1f} {tb * 1e6 / us:5.2f}")
+        tot_us += us
+        tot_bound += tb * 1e6
+    lines.append(f"# total {tot_us:.1f} us measured, {tot_bound:.1f} us bound, fraction {tot_bound / tot_us:.3f}")
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
 
 
 def main():
@@ -234,7 +334,14 @@ def main():
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-launch event passes")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight per GPU, each on a HIP stream of its own (1: one batch after the other)")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the rank(s) through torch.distributed.run even for --gpus 1")
+    ap.add_argument("--layer-table", default=None,
+                    help="write the per-launch roofline table (time, FLOP, bytes, bound, fraction) to this file")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -246,6 +353,8 @@ def main():
         tail = ["--height", str(args.height), "--batch", str(args.batch), "--conf", str(args.conf),
                 "--nms", str(args.nms)]
         traffic, traffic_note = measure_traffic(tail)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -255,7 +364,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks"
 
     import gen_inputs as gi
     from yolo_amd.dist import gather_detections
@@ -342,9 +451,9 @@ def main():
     conv_ms = float(np.mean([e[0].elapsed_time(e[2]) for e in plan.stage_events]))
     nms_ms = float(np.mean([a.elapsed_time(b) for a, b in nms_events]))
     plan.stage_events = None
-    kernels = None
+    kernels = per_launch = None
     if rank == 0 and not args.no_kernel_pass:
-        kernels = kernel_pass(plan, max(3, min(args.steps, 10)))
+        kernels, per_launch = kernel_pass(plan, max(3, min(args.steps, 10)))
     n_rows = 0 if isinstance(out, int) else int(out.shape[0])
     if distributed:
         # outside the timed region: the rows of all ranks in single-process order
@@ -390,7 +499,7 @@ def main():
             n_prof = max(1, sum(t["launches_profiled"] for t in traffic.values()))
             stack["traffic"] = round(sum((t["read_bytes_per_launch"] + t["write_bytes_per_launch"]) *
                                          t["launches_profiled"] for t in traffic.values()) / n_prof)
-        roofline, conv_kernels = dict(stack), None
+        roofline, conv_kernels, scale = dict(stack), None, 1.0
         if kernels:
             # An event between two launches costs about 3 us of stream time, so the
             # per-launch intervals sum to more than the stack takes inside the timed
@@ -426,6 +535,23 @@ def main():
         roofline["traffic_note"] = traffic_note if not traffic else \
             "rocprofv3 --pmc TCC_EA0_RDREQ/_32B and TCC_EA0_WRREQ/_64B, two child passes over this script; " \
             "128 B per non-32B read request, 64/32 B per write request; bytes per launch of this kernel"
+        # ---- the per-layer bound (MFMA for the 3x3 layers, HBM for most 1x1 layers)
+        layers = composite_roofline(plan.ops, B)
+        t_bound = sum(r["t_bound"] for r in layers)
+        t_mfma_only = sum(r["t_mfma"] for r in layers)
+        composite = {"bound": "per layer max(FLOPs / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s), summed over "
+                              f"the {len(layers)} conv layers",
+                     "layers_mfma_bound": sum(1 for r in layers if r["bound"] == "mfma"),
+                     "layers_hbm_bound": sum(1 for r in layers if r["bound"] == "hbm"),
+                     "algorithmic_gbytes_per_step": round(sum(r["bytes"] for r in layers) / 1e9, 3),
+                     "bound_ms_per_step": round(1e3 * t_bound, 4),
+                     "bound_images_per_sec_per_gpu": round(B / t_bound, 1),
+                     "mfma_only_bound_images_per_sec_per_gpu": round(B / t_mfma_only, 1),
+                     "frac_of_composite": round(value / world / (B / t_bound), 4),
+                     "frac_of_mfma_only": round(value / world / (B / t_mfma_only), 4),
+                     "conv_stack_serial_frac_of_composite": round(1e3 * t_bound / conv_ms, 4)}
+        if per_launch and args.layer_table:
+            write_layer_table(args.layer_table, plan, layers, per_launch, scale, B, H)
         pred_bytes = float(B) * N * (5 + C) * 4
         result = {
             "metric": "images/sec (node) YOLOv3-416 end-to-end incl. NMS",
@@ -443,6 +569,7 @@ def main():
                               "roofline_stack and the per-kernel figures are measured in)"},
             "roofline": roofline,
             "roofline_stack": stack,
+            "roofline_composite": composite,
             "stages_ms": {"conv_stack": round(conv_ms, 4), "nms": round(nms_ms, 4)},
             "nms": {"us_per_img": round(1e3 * nms_ms / B, 3),
                     "achieved_gbs": round(pred_bytes / (nms_ms * 1e-3) / 1e9, 1), "peak_gbs": HBM_PEAK_GBS,

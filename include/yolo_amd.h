@@ -95,7 +95,11 @@ int yolo_amd_filter_results(const float* pred, int B, int N, int D, int C, float
  * address (hipGetSymbolAddress) -- make that call outside a graph capture.
  * Same kernels, same rows, bit for bit, as yolo_amd_filter_results.
  * Every call on one GPU uses that GPU's one array: calls that overlap in time
- * on one GPU (two streams) race; queue them on one stream. */
+ * on one GPU (two streams) would race; queue them on one stream.  The library
+ * guards the common case: a call on a stream other than the previous call's,
+ * while that call's kernels have not finished, returns -5 (busy) and launches
+ * nothing.  (Set-up on the first call per device also creates the event the
+ * guard uses; calls queued under graph capture are not tracked by it.) */
 #define YOLO_AMD_STATIC_SCRATCH_BYTES (16u << 20)
 int yolo_amd_filter_results_static(const float* pred, int B, int N, int D, int C, float conf,
                                    float nms_thresh, float* out_rows, int* out_count, void* stream);

@@ -117,7 +117,14 @@ def layer_table(blocks, channels, num_classes, num_anchors,
 # --------------------------------------------------------------------------
 # forward (torch CPU fp32 ops)
 # --------------------------------------------------------------------------
-def forward(state_dict, blocks, params, x, return_layers=False, training=False):
+def _round_bf16(t):
+    """fp32 -> nearest bf16 (ties to even) -> fp32: what storing an activation or a
+    weight as bf16 does to it."""
+    import torch
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def forward(state_dict, blocks, params, x, return_layers=False, training=False, emulate_bf16=False):
     """yolo_v3.forward with is_training=False (yolo_v3.py:449-496).  ``state_dict``
     uses the reference's key names (module_list.<i>.conv_<i>.weight,
     module_list.<i>.bach_norm_<i>.*).  ``x`` is a (B, C, H, H) float32 torch tensor
@@ -129,20 +136,53 @@ def forward(state_dict, blocks, params, x, return_layers=False, training=False):
     biased variance and moves running_mean / running_var (momentum 0.1, unbiased
     variance) and num_batches_tracked; the moved statistics are written back into
     ``state_dict`` (new tensors: the caller's originals are not modified in place).
-    """
+
+    emulate_bf16=True (eval() only) is the same network with the storage roundings of
+    the bf16 device path put in, and nothing else changed: BatchNorm folded into the
+    convolution (scale = gamma / sqrt(var + eps) into the weights, the rest into an fp32
+    bias), folded weights rounded to bf16 except those of the layer that reads the fp32
+    image, sums accumulated in fp32, and every layer's output rounded ONCE to bf16 after
+    bias, LeakyReLU and the shortcut add that follows it; the convolutions in front of
+    the yolo blocks keep their fp32 sums, which are decoded in fp32.  It answers one
+    question for the tests: how far is a bf16 kernel from what bf16 storage alone gives.
+    The reference has no such mode (it is an fp32 program); this is a derived checker."""
     import torch
     import torch.nn.functional as F
 
+    if emulate_bf16 and training:
+        raise ValueError("emulate_bf16 restates the folded (eval) path only")
     C, A = params["num_classes"], params["num_anchors"]
     table = layer_table(blocks, params["channels"], C, A)
     anchors = np.asarray(params["anchors"], dtype=np.float64)
     outs = [None] * len(table)
     dets = []
     x = x.to(torch.float32)
+    reads_image = True                 # the next convolution reads the network input
     with torch.no_grad():
         for i, ent in enumerate(table):
             t = ent["type"]
-            if t == "conv":
+            nxt = table[i + 1]["type"] if i + 1 < len(table) else None
+            if t == "conv" and emulate_bf16:
+                w = state_dict[f"module_list.{i}.conv_{i}.weight"].to(torch.float32)
+                b = state_dict.get(f"module_list.{i}.conv_{i}.bias")
+                if ent["bn"]:
+                    p = f"module_list.{i}.bach_norm_{i}."
+                    scale = state_dict[p + "weight"].float() / torch.sqrt(state_dict[p + "running_var"].float() + 1e-5)
+                    bias = state_dict[p + "bias"].float() - state_dict[p + "running_mean"].float() * scale
+                    if b is not None:
+                        bias = bias + b.float() * scale
+                    w = w * scale.view(-1, 1, 1, 1)
+                else:
+                    bias = b.float() if b is not None else torch.zeros(w.shape[0])
+                if not reads_image:
+                    w = _round_bf16(w)
+                x = F.conv2d(x, w, bias, stride=ent["stride"], padding=ent["pad"])
+                if ent["leaky"]:
+                    x = F.leaky_relu(x, 0.1)
+                if nxt not in ("shortcut", "yolo"):
+                    x = _round_bf16(x)
+                reads_image = False
+            elif t == "conv":
                 w = state_dict[f"module_list.{i}.conv_{i}.weight"]
                 b = state_dict.get(f"module_list.{i}.conv_{i}.bias")
                 x = F.conv2d(x, w, b, stride=ent["stride"], padding=ent["pad"])
@@ -173,6 +213,8 @@ def forward(state_dict, blocks, params, x, return_layers=False, training=False):
                     x = torch.cat((outs[ent["srcs"][0]], outs[ent["srcs"][1]]), 1)
             elif t == "shortcut":
                 x = x + outs[ent["src"]]
+                if emulate_bf16:
+                    x = _round_bf16(x)
             elif t == "yolo":
                 k = ent["head"]
                 head_anchors = anchors[k * A:(k + 1) * A]

@@ -56,10 +56,13 @@ def build_model(H, C=80, A=3, seed=3, confidence=0.5, nms=0.4):
     return model, params, sd
 
 
-def oracle_forward(sd, H, C, A, x_np, return_layers=False):
+def oracle_forward(sd, H, C, A, x_np, return_layers=False, emulate_bf16=False):
+    """The CPU oracle's forward pass: fp32 as the reference computes it, or
+    (emulate_bf16) with the storage roundings of the bf16 device path put in."""
     blocks = orc.parse_cfg_text(yolov3_cfg_text(C, A))
     p = default_params(H, C, A)
-    return orc.forward(sd, blocks, p, torch.from_numpy(x_np), return_layers=return_layers)
+    return orc.forward(sd, blocks, p, torch.from_numpy(x_np), return_layers=return_layers,
+                       emulate_bf16=emulate_bf16)
 
 
 def run_conv(x0, w, bias, *, stride=1, leaky=True, x1=None, up0=0, residual=None, fp32_out=False,

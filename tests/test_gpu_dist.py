@@ -45,6 +45,25 @@ def test_bench_runs_its_distributed_path_with_one_rank(monkeypatch):
     assert not torch.distributed.is_initialized()       # the group was torn down again
 
 
+def test_bench_launches_itself_when_started_without_a_launcher():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment is how a driver starts
+    it: the script then starts its ranks itself (torch.distributed.run as a child process,
+    before this process has touched the GPU) and relays rank 0's JSON line.  Run here with one
+    rank (--spawn takes the same route for N = 1)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "YOLO_AMD_BENCH_FORCE_DIST")}
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--spawn", "--steps", "2",
+                           "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-pipelined", "--no-traffic",
+                           "--no-kernel-pass"], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert "starting 1 rank(s) with torch.distributed.run" in proc.stderr
+    line = [l for l in proc.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["detections_last_step"] > 0
+    assert res["roofline_composite"]["bound_images_per_sec_per_gpu"] > res["value"]
+
+
 def test_gather_detections_on_device_tensors():
     import torch.distributed as dist
     from yolo_amd.dist import gather_detections

@@ -56,6 +56,30 @@ def test_decode_overflow_and_predict_method():
     np.testing.assert_allclose(got[fin], want[fin], rtol=1e-5, atol=1e-6)
 
 
+def test_decode_large_and_saturating_logits():
+    """The decode uses the hardware exp2 / reciprocal, not expf and an IEEE division: its
+    contract is 1e-5 relative, and the error of exp(x) grows with |x|.  Logits of 10-20 in
+    every column, the whole normal range of exp (|x| up to 87) and saturating values stay
+    inside the contract; overflow gives inf, underflow 0, as in the reference."""
+    from yolo_amd.yolo_v3 import decode_heads
+    H, C, A, G = 416, 80, 3, 13
+    p = default_params(H, C, A)
+    r = gi.rs(4242)
+    raw = (r.uniform(10.0, 20.0, (2, A * (5 + C), G, G)) * r.choice([-1.0, 1.0], (2, A * (5 + C), G, G)))
+    raw = raw.astype(np.float32)
+    special = np.array([30.0, -30.0, 60.0, -60.0, 87.0, -87.0, 88.5, -88.5, 100.0, -100.0, 1000.0, -1000.0,
+                        0.0, -0.0, 1e-30, 16.635532, -16.635532], dtype=np.float32)
+    for ch in range(A * (5 + C)):                    # every column type sees every special value
+        raw[1, ch].reshape(-1)[:special.size] = np.roll(special, ch)
+    anchors = p["anchors"][:A]
+    got = decode_heads([torch.from_numpy(raw).cuda()], [anchors], H, C).cpu().numpy()
+    want = c_decode_head(raw, anchors, H, C)
+    assert np.array_equal(np.isinf(got), np.isinf(want)) and np.isinf(want).sum() > 0
+    assert not np.isnan(got).any()
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(got[fin], want[fin], rtol=1e-5, atol=1e-6)
+
+
 def test_decode_full_size_vs_c_oracle():
     from yolo_amd.yolo_v3 import decode_heads
     p = default_params(416)
@@ -329,6 +353,7 @@ def test_forward_layers_and_output(case):
     torch.cuda.synchronize()
     assert torch.equal(det_keep, det), "buffer placement changes the result"
     worst = 0.0
+    _, outs16 = oracle_forward(sd, H, C, A, x_np, return_layers=True, emulate_bf16=True)
     for op in plan.ops:
         i = op["index"]
         ref = outs[i + 1] if op["res"] else outs[i]          # fused shortcut: compare after the add
@@ -336,7 +361,10 @@ def test_forward_layers_and_output(case):
         got = plan.layer_output(i).float().cpu().numpy()
         err = _rel_err(got, ref)
         worst = max(worst, err)
-        assert err < 0.03, f"conv block {i}: relative L2 error {err:.4f} vs the fp32 oracle"
+        assert err < 0.02, f"conv block {i}: relative L2 error {err:.4f} vs the fp32 oracle"
+        ref16 = (outs16[i + 1] if op["res"] else outs16[i]).permute(0, 2, 3, 1).numpy()
+        err16 = _rel_err(got, ref16)
+        assert err16 < 3e-3, f"conv block {i}: relative L2 error {err16:.5f} vs the oracle with bf16 storage"
     got = det.cpu().numpy()
     want = want.numpy()
     if case["name"] in ARR:
@@ -376,24 +404,45 @@ def test_forward_416_vs_oracle_and_end_to_end(conv3, monkeypatch):
 
 
 # ------------------------------------------------------------------ the benchmark configurations
-# bf16 bar: boxes and scores within 1e-2 relative of the fp32 reference path.  What is
-# gated: the per-layer relative L2 error (3e-2), the share of output elements inside
-# 1e-2 relative (rel = |got - want| / (|want| + 1e-3)), the objectness error, and
-# bit-exact NMS rows given the HIP prediction.  The shares and the bf16-vs-fp32
-# keep-set agreement (Jaccard index of the kept (image, box) pairs) are written to
-# gpurun_out/parity_metrics.json; the committed copy is profiles/round2_parity_metrics.json.
-# Measured on MI355X: 0.77-0.79 of all output elements are inside 1e-2 relative (median
-# relative error 4e-3, 99th percentile 3e-2, objectness off by at most 0.02): 75 layers
-# of activations stored as bf16 (2^-9 relative rounding each, about fifty of them at
-# full weight) random-walk to a relative L2 error of 1.5e-2 at the heads, which is
-# what bf16 storage costs whatever the kernels do.  The gate sits just under that.
+# bf16 bar: boxes and scores within 1e-2 relative of the reference path.  Two oracles, two questions.
+#
+# (1) Against the oracle with the device path's storage roundings put in (bf16 folded weights,
+#     every fused layer's output rounded once to bf16, fp32 sums, fp32 detection convolutions
+#     and decode): what is left is what the KERNELS add (summation order, the hardware exp /
+#     reciprocal of the decode).  Gated: per-layer relative L2 < 3e-3 and >= 99 % of all output
+#     elements within 1e-2 relative (rel = |got - want| / (|want| + 1e-3)).
+# (2) Against the fp32 oracle (= the reference): what bf16 STORAGE costs end to end.  Gated per
+#     layer at 2e-2 relative L2 (the worst layer measures 1.5e-2) and on the median and the
+#     objectness error; the share inside 1e-2 and the bf16-vs-fp32 keep-set agreement (Jaccard
+#     index of the kept (image, box) pairs) are reported.
+# NMS rows are bit-exact given the HIP prediction.  Everything measured goes to
+# gpurun_out/parity_metrics.json (a copy is committed under profiles/).
 CONFIG_CASES = [
-    # name, H, B, C, A, minimum share of elements within 1e-2 relative
-    ("cfg2_416_b32", 416, 32, 80, 3, 0.72),         # the benchmark configuration: batch-32 dispatch
-    ("cfg3_608_b2", 608, 2, 80, 3, 0.72),           # 19 * 2^n maps: ragged im2col tiles, 19 x 10 patch tiles
-    ("cfg5a_320_b1", 320, 1, 80, 3, 0.72),          # video latency: split reductions
-    ("cfg5b_320_b1_a1c4", 320, 1, 4, 1, 0.72),      # one-anchor variant
+    # name, H, B, C, A
+    ("cfg2_416_b32", 416, 32, 80, 3),         # the benchmark configuration: batch-32 dispatch
+    ("cfg3_608_b32", 608, 32, 80, 3),         # one GPU's share of the 8-GPU configuration: 19 x 10 patch tiles on every map
+    ("cfg3_608_b2", 608, 2, 80, 3),           # 19 * 2^n maps at a small batch: ragged im2col tiles
+    ("cfg5a_320_b1", 320, 1, 80, 3),          # video latency: split reductions
+    ("cfg5b_320_b1_a1c4", 320, 1, 4, 1),      # one-anchor variant
 ]
+BF16_ORACLE_LAYER_GATE = 3e-3
+BF16_ORACLE_SHARE_GATE = 0.99
+FP32_ORACLE_LAYER_GATE = 2e-2
+
+
+def _layer_errors(keep, outs):
+    """Relative L2 error of every conv launch's output (after the fused shortcut add) against
+    the oracle's per-block outputs, computed on the GPU in float64."""
+    errs = {}
+    for op in keep.ops:
+        i = op["index"]
+        ref = (outs[i + 1] if op["res"] else outs[i]).permute(0, 2, 3, 1).contiguous().cuda()
+        got = keep.layer_output(i).float()
+        num = torch.linalg.vector_norm((got - ref).flatten(), dtype=torch.float64)
+        den = torch.linalg.vector_norm(ref.flatten(), dtype=torch.float64)
+        errs[i] = float(num / (den + 1e-30))
+        del ref, got
+    return errs
 
 
 @pytest.mark.parametrize("case", CONFIG_CASES, ids=lambda c: c[0])
@@ -402,7 +451,7 @@ def test_forward_benchmark_configurations(case):
     from yolo_amd import _lib
     from yolo_amd.engine import Plan
     from yolo_amd.utilis import filter_results
-    name, H, B, C, A, min_share = case
+    name, H, B, C, A = case
     model, params, sd = build_model(H, C, A)
     x_np = gi.images(21, B, H)
     x = torch.from_numpy(x_np).cuda()
@@ -413,11 +462,13 @@ def test_forward_benchmark_configurations(case):
 
     # which kernels the default plan of this configuration runs
     plan = model._plan(B, H)
-    kinds = {}
+    kinds, patch_small_maps = {}, 0
     for j in range(len(plan.ops)):
         ch = _lib.conv_choice(plan.descs[j])
         key = (ch["kernel"], ch["bn"], ch["bk"], ch["act_ksteps"]) if ch["kernel"] == "igemm" else (ch["kernel"],)
         kinds[key] = kinds.get(key, 0) + 1
+        if ch["kernel"] == "patch" and plan.ops[j]["Ho"] in (19, 38):
+            patch_small_maps += 1
     print(f"\n{name}: kernels {kinds}")
     if name == "cfg2_416_b32":
         assert kinds.get(("igemm", 128, 32, 2), 0) >= 10, "batch 32 was meant to run the 128-channel-tile kernel"
@@ -425,28 +476,43 @@ def test_forward_benchmark_configurations(case):
     if name == "cfg3_608_b2":
         # 19 x 10 tiles on the 152^2 and 76^2 maps; the smaller maps have too few tiles at batch 2
         assert kinds.get(("patch",), 0) >= 8
+    if name == "cfg3_608_b32":
+        assert kinds.get(("patch",), 0) >= 25
+        assert patch_small_maps >= 8, "at batch 32 the 19^2 / 38^2 maps were meant to take the 19 x 10 patch tiles"
 
-    want_t, outs = oracle_forward(sd, H, C, A, x_np, return_layers=True)
     keep = Plan(model, B, H, keep_all=True)
     det_keep = keep.run(x)
     torch.cuda.synchronize()
-    worst = 0.0
-    for op in keep.ops:
-        i = op["index"]
-        ref = outs[i + 1] if op["res"] else outs[i]
-        err = _rel_err(keep.layer_output(i).float().cpu().numpy(), ref.permute(0, 2, 3, 1).numpy())
-        worst = max(worst, err)
-        assert err < 0.03, f"conv block {i}: relative L2 error {err:.4f} vs the fp32 oracle"
-    del outs, keep
-    got, want = det.cpu().numpy(), want_t.numpy()
     # the layer-by-layer plan runs the first two layers separately and its own decode
     # launch: same values as the fused plan
     assert torch.equal(det_keep, det), "fused stem / fused decode change the result"
-    rel = np.abs(got - want) / (np.abs(want) + 1e-3)
-    share = float((rel <= 1e-2).mean())
-    share_box = float((rel[..., :4] <= 1e-2).mean())
-    share_obj = float((rel[..., 4] <= 1e-2).mean())
+    got = det.cpu().numpy()
+
+    # (2) the fp32 oracle = the reference's arithmetic
+    want_t, outs = oracle_forward(sd, H, C, A, x_np, return_layers=True)
+    errs32 = _layer_errors(keep, outs)
+    del outs
+    worst32 = max(errs32.values())
+    for i, err in errs32.items():
+        assert err < FP32_ORACLE_LAYER_GATE, f"conv block {i}: relative L2 error {err:.4f} vs the fp32 oracle"
+    want = want_t.numpy()
+    # (1) the oracle with bf16 storage
+    want16_t, outs = oracle_forward(sd, H, C, A, x_np, return_layers=True, emulate_bf16=True)
+    errs16 = _layer_errors(keep, outs)
+    del outs, keep
+    worst16_block = max(errs16, key=errs16.get)
+    worst16 = errs16[worst16_block]
+    want16 = want16_t.numpy()
+
+    def shares(ref):
+        rel = np.abs(got - ref) / (np.abs(ref) + 1e-3)
+        return rel, dict(all=float((rel <= 1e-2).mean()), boxes=float((rel[..., :4] <= 1e-2).mean()),
+                         objectness=float((rel[..., 4] <= 1e-2).mean()), scores=float((rel[..., 5:] <= 1e-2).mean()))
+    rel16, share16 = shares(want16)
+    rel, share32 = shares(want)
     obj_err = float(np.abs(got[..., 4] - want[..., 4]).max())
+    obj_err16 = float(np.abs(got[..., 4] - want16[..., 4]).max())
+
     out = filter_results(det, params)
     rows = c_filter_results(got, params["confidence"], params["nms_thesh"], C)
     if rows.shape[0] == 0:
@@ -454,16 +520,39 @@ def test_forward_benchmark_configurations(case):
     else:
         assert_bit_equal(out.cpu().numpy(), rows, f"{name}: NMS rows given the HIP prediction")
     ref_rows = c_filter_results(want, params["confidence"], params["nms_thesh"], C)
-    ks_hip, ks_ref = keep_set(got, rows), keep_set(want, ref_rows)
+    ref16_rows = c_filter_results(want16, params["confidence"], params["nms_thesh"], C)
+    ks_hip, ks_ref, ks_ref16 = keep_set(got, rows), keep_set(want, ref_rows), keep_set(want16, ref16_rows)
     jac = len(ks_hip & ks_ref) / max(1, len(ks_hip | ks_ref))
-    metrics = dict(H=H, B=B, C=C, A=A, worst_layer_rel_l2=round(worst, 5), share_within_1e2=round(share, 5),
-                   share_within_1e2_boxes=round(share_box, 5), share_within_1e2_objectness=round(share_obj, 5),
-                   median_rel=float(np.median(rel)), p99_rel=float(np.percentile(rel, 99)),
-                   objectness_abs_err_max=obj_err, rows_hip=int(rows.shape[0]), rows_fp32=int(ref_rows.shape[0]),
-                   keep_set_jaccard=round(jac, 5), kernels={"/".join(map(str, k)): v for k, v in kinds.items()})
+    jac16 = len(ks_hip & ks_ref16) / max(1, len(ks_hip | ks_ref16))
+    w = want[..., 4]
+    metrics = dict(H=H, B=B, C=C, A=A,
+                   vs_bf16_oracle=dict(worst_layer_rel_l2=round(worst16, 6), worst_layer_block=int(worst16_block),
+                                       share_within_1e2=round(share16["all"], 5),
+                                       share_within_1e2_boxes=round(share16["boxes"], 5),
+                                       share_within_1e2_objectness=round(share16["objectness"], 5),
+                                       share_within_1e2_scores=round(share16["scores"], 5),
+                                       median_rel=float(np.median(rel16)), p99_rel=float(np.percentile(rel16, 99)),
+                                       max_rel=float(rel16.max()), objectness_abs_err_max=obj_err16,
+                                       rows_oracle=int(ref16_rows.shape[0]), keep_set_jaccard=round(jac16, 5)),
+                   vs_fp32_oracle=dict(worst_layer_rel_l2=round(worst32, 5), share_within_1e2=round(share32["all"], 5),
+                                       share_within_1e2_boxes=round(share32["boxes"], 5),
+                                       share_within_1e2_objectness=round(share32["objectness"], 5),
+                                       median_rel=float(np.median(rel)), p99_rel=float(np.percentile(rel, 99)),
+                                       objectness_abs_err_max=obj_err, rows_oracle=int(ref_rows.shape[0]),
+                                       keep_set_jaccard=round(jac, 5)),
+                   objectness_fp32_oracle=dict(min=float(w.min()), p01=float(np.percentile(w, 1)),
+                                               median=float(np.median(w)), p99=float(np.percentile(w, 99)),
+                                               max=float(w.max()),
+                                               share_within_0p02_of_conf=float(
+                                                   (np.abs(w - params["confidence"]) <= 0.02).mean())),
+                   rows_hip=int(rows.shape[0]),
+                   kernels={"/".join(map(str, k)): v for k, v in kinds.items()})
     print(f"{name}: {metrics}")
     record_metric(name, metrics)
-    assert share >= min_share, f"only {share:.3f} of the output elements are within 1e-2 relative"
+    assert worst16 < BF16_ORACLE_LAYER_GATE, \
+        f"conv block {worst16_block}: relative L2 error {worst16:.5f} vs the oracle with bf16 storage"
+    assert share16["all"] >= BF16_ORACLE_SHARE_GATE, \
+        f"only {share16['all']:.4f} of the output elements are within 1e-2 relative of the oracle with bf16 storage"
     assert np.median(rel) < 1e-2 and obj_err < 0.05
 
 

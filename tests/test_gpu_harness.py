@@ -163,6 +163,61 @@ def test_detection_pipeline_with_a_partial_last_batch_and_unclone_results():
     assert n_checked == len(batches) - 3
 
 
+def test_rows_are_ordered_behind_the_launch_stream_for_a_consumer_on_another_stream():
+    """filter_results_async on a lane stream, result() on the default stream: the row count
+    reaches the host before the kernel that writes the rows has run, so result() has to put
+    the consumer's stream behind the lane's last kernel (a device-side event wait) and keep
+    the allocator from recycling the rows under it.  The lane is held back by a spin kernel
+    so that everything is still queued when result() is called."""
+    from yolo_amd import utilis
+    from yolo_amd.utilis import filter_results, filter_results_async
+    pred_np = gi.nms_pred(61, 4, 3000, 80, H=416, mode="clustered")
+    pred = torch.from_numpy(pred_np).cuda()
+    params = default_params(416, 80, 3, confidence=0.3, nms_thesh=0.4)
+    want = filter_results(pred, params).clone()
+    torch.cuda.synchronize()
+    lane = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(lane):
+            torch.cuda._sleep(20_000_000)                 # ~10 ms ahead of the NMS kernels
+            pending = filter_results_async(pred, params)
+        assert not pending.done()
+        rows = pending.result()                            # on the default stream
+        got = rows.clone()                                 # a default-stream kernel reading the rows
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+
+
+def test_a_dropped_pending_result_keeps_its_host_counter_out_of_circulation():
+    """The scan kernel stores the row count straight into a pinned host word.  A
+    PendingDetections dropped before its kernels have run must not hand that word back for
+    reuse: it is parked until the launch stream's event has completed."""
+    import gc
+    from yolo_amd.utilis import _HostCount, filter_results, filter_results_async
+    pred = torch.from_numpy(gi.nms_pred(62, 2, 2000, 80, H=416, mode="uniform")).cuda()
+    params = default_params(416, 80, 3, confidence=0.4, nms_thesh=0.4)
+    filter_results(pred, params)
+    torch.cuda.synchronize()
+    _HostCount.take().give_back()                         # drains the parked list of earlier tests
+    parked = len(_HostCount._limbo)
+    lane = torch.cuda.Stream()
+    with torch.cuda.stream(lane):
+        torch.cuda._sleep(20_000_000)
+        pending = filter_results_async(pred, params)
+    host = pending._host
+    del pending
+    gc.collect()
+    assert host in _HostCount._limbo and host not in _HostCount._pool
+    assert len(_HostCount._limbo) == parked + 1
+    torch.cuda.synchronize()
+    assert host.ready(), "the kernel's store arrived in the parked counter"
+    other = _HostCount.take()                              # completed counters return to the pool here
+    other.give_back()
+    assert host not in _HostCount._limbo
+    out = filter_results(pred, params)                     # and the path still works
+    assert not isinstance(out, int)
+
+
 @pytest.mark.parametrize("train", [False, True])
 @pytest.mark.parametrize("name", ["coco_sweep", "four_class", "single_conf"])
 def test_get_map_with_hip_detections_matches_the_reference(name, train):

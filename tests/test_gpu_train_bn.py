@@ -219,6 +219,50 @@ def test_train_mode_at_the_video_callers_size():
     _compare_outputs(got.cpu().numpy(), mod, "HIP path vs torch modules")
 
 
+def test_train_mode_passes_on_two_streams_run_one_after_the_other():
+    """A pipeline with batches in flight on several streams over a model that never called
+    eval(): every pass moves the modules' running statistics with read-modify-writes, so the
+    passes must not overlap.  The statistics and the outputs after four batches through the
+    two-lane pipeline equal, bit for bit, those of the same four batches on one stream."""
+    from yolo_amd.harness import DetectionPipeline
+    from yolo_amd.utilis import filter_results
+    H, B = 96, 2
+    xs = [torch.from_numpy(gi.images(400 + i, B, H)).cuda() for i in range(4)]
+
+    def run(pipelined):
+        model, params, _ = build_model(H, 80, 3, seed=3)
+        params = dict(params)
+        params["confidence"] = 0.3
+        model.train()
+        outs = []
+        if pipelined:
+            pipe = DetectionPipeline(model, params, depth=2)
+            for x in xs:
+                outs += pipe.submit(x)
+            outs += pipe.flush()
+        else:
+            for x in xs:
+                outs.append(filter_results(model(x), params))
+        torch.cuda.synchronize()
+        assert sum(1 for key in model._plans if key[3]) == 1, "one batch-statistics plan for all streams"
+        stats = {k: v.clone() for k, v in model.state_dict().items() if "bach_norm" in k}
+        return [o if isinstance(o, int) else o.clone() for o in outs], stats
+
+    want, want_stats = run(False)
+    got, got_stats = run(True)
+    for k, v in want_stats.items():
+        assert torch.equal(got_stats[k], v), f"{k} differs between the pipelined and the serial run"
+    nbt = [int(v) for k, v in got_stats.items() if k.endswith("num_batches_tracked")]
+    assert nbt and all(n == 4 for n in nbt)
+    assert len(got) == len(want) == 4
+    for g, w in zip(got, want):
+        if isinstance(w, int):
+            assert isinstance(g, int)
+        else:
+            assert torch.equal(g.view(torch.int32), w.view(torch.int32))
+    # ... and the eval() pass that follows folds the moved statistics, whatever stream moved them
+
+
 def test_the_training_loss_path_is_not_offered():
     model, params, _ = build_model(64)
     x = torch.from_numpy(gi.images(12, 2, 64)).cuda()

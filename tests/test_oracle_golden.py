@@ -148,6 +148,41 @@ def test_forward_oracle_matches_reference(case):
         assert_bit_equal(got, ARR[case["name"] + "_e2e"], "e2e rows")
 
 
+def test_forward_oracle_with_bf16_storage():
+    """emulate_bf16 changes nothing but the storage roundings: every stored activation is a
+    bf16 value, every layer stays within bf16 distance of the fp32 oracle, and the default
+    (fp32, pinned to the reference above) is untouched by the option."""
+    case = next(c for c in META["forward_cases"] if "h64" in c["name"])
+    H, B, C, A = case["H"], case["B"], case["C"], case["A"]
+    blocks = orc.parse_cfg_text(yolov3_cfg_text(C, A))
+    p = default_params(H, C, A)
+    table = orc.layer_table(blocks, 3, C, A)
+    sd = {k: torch.from_numpy(np.asarray(v))
+          for k, v in gi.synthetic_state_dict(table, case["weight_seed"]).items()}
+    x = torch.from_numpy(gi.images(case["image_seed"], B, H))
+    det32, outs32 = orc.forward(sd, blocks, p, x, return_layers=True)
+    det16, outs16 = orc.forward(sd, blocks, p, x, return_layers=True, emulate_bf16=True)
+    np.testing.assert_allclose(det32.numpy(), ARR[case["name"]], rtol=1e-5, atol=1e-5)
+    assert det16.shape == det32.shape and not torch.equal(det16, det32)
+    n_checked = 0
+    for i, ent in enumerate(table):
+        if ent["type"] not in ("conv", "shortcut") or outs16[i] is None:
+            continue
+        nxt = table[i + 1]["type"] if i + 1 < len(table) else None
+        o16, o32 = outs16[i], outs32[i]
+        stored = ent["type"] == "shortcut" or nxt not in ("shortcut", "yolo")
+        if stored:       # what the device path writes to memory: exactly representable in bf16
+            assert torch.equal(o16.to(torch.bfloat16).float(), o16), f"block {i} holds non-bf16 values"
+            n_checked += 1
+        err = float((o16 - o32).double().norm() / o32.double().norm())
+        assert err < 2e-2, f"block {i}: bf16 storage moved the layer by {err:.4f} relative L2"
+    assert n_checked >= 72
+    rel = (det16 - det32).abs() / (det32.abs() + 1e-3)
+    assert float(rel.median()) < 1e-2
+    with pytest.raises(ValueError):
+        orc.forward(sd, blocks, p, x, training=True, emulate_bf16=True)
+
+
 # ---- train() mode: BatchNorm2d on batch statistics (video.py / get_fps.py never call eval())
 import json as _json
 import os as _os

@@ -67,3 +67,39 @@ def test_static_scratch_entry_point_rejects_what_does_not_fit():
     rc = lib.yolo_amd_filter_results_static(pred.data_ptr(), 3, 10647, 85, 80, 0.5, 0.4, rows.data_ptr(),
                                             cnt.data_ptr(), None)
     assert rc < 0
+
+
+def test_static_scratch_entry_point_refuses_a_second_stream_while_the_first_is_busy():
+    """One scratch array per GPU: a call on another stream while the previous call's kernels
+    are still queued would corrupt both, so it is refused (-5) and launches nothing; the same
+    call succeeds once the first stream has drained, and a call on the SAME stream never waits."""
+    from yolo_amd._lib import lib
+    pred_np = gi.nms_pred(seed=83, B=1, N=2100, C=4, H=320, mode="clustered")
+    pred = torch.from_numpy(pred_np).cuda()
+    want = _regular(pred, 0.1, 0.4, 4)
+    rows_a = torch.full((2100, 9), float("nan"), dtype=torch.float32, device="cuda")
+    rows_b = torch.full((2100, 9), float("nan"), dtype=torch.float32, device="cuda")
+    cnt_a = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    cnt_b = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(sa):
+        torch.cuda._sleep(40_000_000)                      # keeps stream A busy for ~20 ms
+        rc = lib.yolo_amd_filter_results_static(pred.data_ptr(), 1, 2100, 9, 4, 0.1, 0.4, rows_a.data_ptr(),
+                                                cnt_a.data_ptr(), sa.cuda_stream)
+        assert rc == 0, lib.yolo_amd_last_error()
+        # the same stream again: stream order, no conflict
+        rc = lib.yolo_amd_filter_results_static(pred.data_ptr(), 1, 2100, 9, 4, 0.1, 0.4, rows_a.data_ptr(),
+                                                cnt_a.data_ptr(), sa.cuda_stream)
+        assert rc == 0, lib.yolo_amd_last_error()
+    rc = lib.yolo_amd_filter_results_static(pred.data_ptr(), 1, 2100, 9, 4, 0.1, 0.4, rows_b.data_ptr(),
+                                            cnt_b.data_ptr(), sb.cuda_stream)
+    assert rc == -5 and b"another stream" in lib.yolo_amd_last_error()
+    torch.cuda.synchronize()
+    assert int(cnt_b.item()) == -1, "the refused call launched something"
+    assert_bit_equal(rows_a[:int(cnt_a.item())].cpu().numpy(), want, "stream A's rows")
+    rc = lib.yolo_amd_filter_results_static(pred.data_ptr(), 1, 2100, 9, 4, 0.1, 0.4, rows_b.data_ptr(),
+                                            cnt_b.data_ptr(), sb.cuda_stream)
+    assert rc == 0, lib.yolo_amd_last_error()
+    torch.cuda.synchronize()
+    assert_bit_equal(rows_b[:int(cnt_b.item())].cpu().numpy(), want, "stream B's rows after A had drained")

@@ -1013,6 +1013,12 @@ static __device__ __align__(256) unsigned char scratch[YOLO_AMD_STATIC_SCRATCH_B
 
 constexpr int MAX_DEVICES = 64;
 static void* g_scratch_ptr[MAX_DEVICES];           // per device: where `scratch` lives there
+// Per device: the stream of the last call and an event recorded behind its kernels, so
+// that a call on ANOTHER stream while that work may still be running (the one way two
+// users of the one array can overlap) is refused instead of silently corrupting both.
+static hipStream_t g_scratch_stream[MAX_DEVICES];
+static hipEvent_t g_scratch_event[MAX_DEVICES];
+static bool g_scratch_pending[MAX_DEVICES];
 static std::mutex g_scratch_mutex;
 
 extern "C" int yolo_amd_filter_results_static(const float* pred, int B, int N, int D, int C, float conf,
@@ -1029,19 +1035,44 @@ extern "C" int yolo_amd_filter_results_static(const float* pred, int B, int N, i
     int dev = -1;
     YA_CHECK_HIP(hipGetDevice(&dev));
     YA_REQUIRE(dev >= 0 && dev < MAX_DEVICES, "filter_results_static: device %d out of range", dev);
-    void* ptr;
-    {
-        std::lock_guard<std::mutex> lock(g_scratch_mutex);
-        if (!g_scratch_ptr[dev]) {
-            void* p = nullptr;
-            YA_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-            YA_REQUIRE(p && ((uintptr_t)p & 255) == 0, "filter_results_static: bad address for the static scratch");
-            g_scratch_ptr[dev] = p;
-        }
-        ptr = g_scratch_ptr[dev];
+    hipStream_t stream = (hipStream_t)stream_;
+    // (held over the launches: two host threads cannot interleave their kernels on the array)
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        // set-up, once per device (make the first call outside a graph capture)
+        void* p = nullptr;
+        YA_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        YA_REQUIRE(p && ((uintptr_t)p & 255) == 0, "filter_results_static: bad address for the static scratch");
+        YA_CHECK_HIP(hipEventCreateWithFlags(&g_scratch_event[dev], hipEventDisableTiming));
+        g_scratch_ptr[dev] = p;
     }
-    return run_filter_results(pred, B, N, D, C, conf, nms_thresh, ptr, (size_t)YOLO_AMD_STATIC_SCRATCH_BYTES,
-                              out_rows, out_count, (hipStream_t)stream_);
+    void* ptr = g_scratch_ptr[dev];
+    if (g_scratch_pending[dev] && g_scratch_stream[dev] != stream) {
+        const hipError_t q = hipEventQuery(g_scratch_event[dev]);
+        if (q == hipErrorNotReady) {
+            set_error("filter_results_static: the previous call on this GPU was queued on another stream and has "
+                      "not finished; the one static scratch cannot serve two streams at once (queue the calls on "
+                      "one stream, or use yolo_amd_filter_results with a workspace per stream)");
+            return YA_ERR_BUSY;
+        }
+        YA_CHECK_HIP(q);
+        g_scratch_pending[dev] = false;
+    }
+    const int rc = run_filter_results(pred, B, N, D, C, conf, nms_thresh, ptr, (size_t)YOLO_AMD_STATIC_SCRATCH_BYTES,
+                                      out_rows, out_count, stream);
+    // Remember where this call's kernels are queued.  A stream under graph capture cannot
+    // carry the guard (an event recorded into a graph cannot be queried): calls replayed
+    // from a graph are the caller's to keep on one stream.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+        if (hipEventRecord(g_scratch_event[dev], stream) == hipSuccess) {
+            g_scratch_stream[dev] = stream;
+            g_scratch_pending[dev] = true;
+        }
+    } else {
+        (void)hipGetLastError();
+    }
+    return rc;
 }
 
 

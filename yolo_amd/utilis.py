@@ -243,23 +243,48 @@ def filter_img_class(cls, image_pred, ind, nms_thesh):
 class _HostCount:
     """A pinned host int32 the scan kernel writes the row count K into directly (pinned
     memory is mapped into the device's address space), so that no copy kernel and no
-    stream synchronisation stand between the last NMS kernel and the host knowing K.
-    The host arms it with -1 and polls; counters are recycled (pinning is slow)."""
+    stream synchronisation stand between the NMS kernels and the host knowing K.
+    The host arms it with -1 and polls; counters are recycled (pinning is slow).
+
+    Every launch records `event` on the launch stream behind the LAST kernel (the gather
+    that writes the rows runs after the scan that publishes K).  Two things hang on it:
+    a consumer on another stream waits for it before touching the rows, and a counter
+    only goes back to the pool once it has completed -- a counter dropped while its
+    kernels are still queued is parked in `_limbo` until then, so that the late store
+    of K can never land in memory that has been handed to somebody else."""
     _pool = []
+    _limbo = []
 
     def __init__(self):
         self.tensor = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.view = self.tensor.numpy()
+        self.event = torch.cuda.Event()
+        self.stream = None
 
     @classmethod
     def take(cls):
+        if cls._limbo:
+            still = []
+            for hc in cls._limbo:
+                (cls._pool if hc.event.query() else still).append(hc)
+            cls._limbo[:] = still
         hc = cls._pool.pop() if cls._pool else cls()
         hc.view[0] = -1
         hc.stream = None
         return hc
 
+    def launched(self, stream):
+        """Call right after the kernels have been queued on `stream`."""
+        self.stream = stream
+        self.event.record(stream)
+
     def give_back(self):
-        _HostCount._pool.append(self)
+        """Return the counter: to the pool if everything queued with it has run, else to
+        the list of counters whose kernels are still in flight."""
+        if self.stream is None or self.event.query():
+            _HostCount._pool.append(self)
+        else:
+            _HostCount._limbo.append(self)
 
     def ready(self):
         return int(self.view[0]) != -1
@@ -282,6 +307,17 @@ class _HostCount:
             raise _lib.YoloAmdError("filter_results: the row count never reached the host")
         return int(view[0])
 
+    def order_rows_behind(self, rows):
+        """Make the rows safe to use on the caller's current stream.  K reaches the host
+        before the gather kernel has written the rows; on the launch stream that is
+        plain stream order, on any other stream the consumer has to wait for the launch
+        stream's event (a device-side wait), and the allocator must not recycle the
+        block under reads queued on that other stream."""
+        cur = torch.cuda.current_stream(rows.device)
+        if self.stream is not None and cur != self.stream:
+            cur.wait_event(self.event)
+            rows.record_stream(cur)
+
 
 def _launch_filter_results(prediction, params):
     """Queue the NMS kernels on the current stream.  Returns (rows buffer, host
@@ -297,13 +333,17 @@ def _launch_filter_results(prediction, params):
     nbytes = lib.yolo_amd_filter_results_workspace_bytes(B, N, C)
     ws = _workspace(pred.device, nbytes)
     cnt = _HostCount.take()
-    cnt.stream = torch.cuda.current_stream(pred.device)
-    with torch.cuda.device(pred.device):
-        check(lib.yolo_amd_filter_results(pred.data_ptr(), B, N, D, C,
-                                          float(params["confidence"]), float(params["nms_thesh"]),
-                                          ws.data_ptr(), ws.numel(), out.data_ptr(), cnt.tensor.data_ptr(),
-                                          _lib.current_stream_ptr(pred.device)),
-              "filter_results")
+    stream = torch.cuda.current_stream(pred.device)
+    try:
+        with torch.cuda.device(pred.device):
+            check(lib.yolo_amd_filter_results(pred.data_ptr(), B, N, D, C,
+                                              float(params["confidence"]), float(params["nms_thesh"]),
+                                              ws.data_ptr(), ws.numel(), out.data_ptr(), cnt.tensor.data_ptr(),
+                                              _lib.current_stream_ptr(pred.device)),
+                  "filter_results")
+    finally:
+        # also after a failed launch: some kernels may have been queued already
+        cnt.launched(stream)
     return out, cnt, dev
 
 
@@ -324,8 +364,11 @@ def filter_results(prediction, params):
     if launched is None:
         return 0
     out, cnt, dev = launched
-    k = cnt.wait()
-    cnt.give_back()
+    try:
+        k = cnt.wait()
+        cnt.order_rows_behind(out)
+    finally:
+        cnt.give_back()
     if k == 0:
         return 0
     res = out[:k]
@@ -344,16 +387,33 @@ class PendingDetections:
         return self._host is None or self._host.ready()
 
     def result(self):
+        """The rows, ready for use on the caller's CURRENT stream (which may differ from
+        the stream the NMS was queued on: the rows are then ordered behind the launch
+        stream's last kernel by a device-side event wait)."""
         if self._rows is None:
             return 0
-        k = self._host.wait()
-        self._host.give_back()
-        self._host = None
+        host, self._host = self._host, None
+        try:
+            k = host.wait()
+            host.order_rows_behind(self._rows)
+        finally:
+            host.give_back()
         res = self._rows[:k] if k else 0
         self._rows = None
         if isinstance(res, int) or self._dev.type == "cuda":
             return res
         return res.to(self._dev)
+
+    def __del__(self):
+        # dropped without result(): the counter stays out of circulation until the
+        # kernels that write to it have run
+        host = getattr(self, "_host", None)
+        if host is not None:
+            self._host = None
+            try:
+                host.give_back()
+            except Exception:      # interpreter shutdown
+                pass
 
 
 def filter_results_async(prediction, params):

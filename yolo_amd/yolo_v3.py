@@ -85,6 +85,7 @@ class yolo_v3(nn.Module):
         self._weights_version = 0
         self._device = None
         self._running_stats_moved = False   # a train()-mode forward has updated them since the last fold
+        self._train_event = None            # recorded behind the last train()-mode forward pass
         if self.params["pretrain_snapshot"]:
             self.load_state_dict(torch.load(self.params["pretrain_snapshot"]))
         elif weight_file is not None:
@@ -122,8 +123,11 @@ class yolo_v3(nn.Module):
         # One plan (activation arena, split-K scratch, descriptors) per shape AND per
         # stream: calls queued on one stream run in order and share it, calls on two
         # streams may overlap on the GPU and get arenas of their own.
+        # A train()-mode plan is the exception: its kernels read and write the modules' own
+        # running statistics, so there is ONE per shape whatever the stream, and forward()
+        # runs such passes strictly one after the other (see _train_event).
         dev = self._param_device()
-        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" and not train else 0
         key = (B, H, stream, train)
         plan = self._plans.get(key)
         if plan is None:
@@ -155,14 +159,30 @@ class yolo_v3(nn.Module):
                               f"model ({exc}); running the torch modules", stacklevel=2)
                 out = self._forward_modules(x)
                 return out if src_device == dev else out.to(src_device)
+            # Batch-statistics passes update running_mean / running_var / num_batches_tracked
+            # with read-modify-writes: two of them side by side on two streams (a pipeline
+            # with several batches in flight over a model that never called eval()) would
+            # lose updates.  Each pass waits for the one before it, on whatever stream that ran.
+            cur = torch.cuda.current_stream(dev)
+            if self._train_event is not None:
+                cur.wait_event(self._train_event)
             self._running_stats_moved = True
             out = plan.run(x)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._train_event = ev
             return out if src_device == dev else out.to(src_device)
         if self._running_stats_moved:
-            # the eval() plans folded running statistics that have changed since
+            # The eval() plans folded running statistics that have changed since.  The
+            # passes that moved them, and eval() passes still reading the old folded
+            # weights on other streams, must be over before the weights are replaced, and
+            # the new ones in place before any stream uses them: a rare transition
+            # (train() -> eval()), so the whole device is synchronised around it.
+            torch.cuda.synchronize(dev)
             for key, plan in self._plans.items():
                 if not key[3]:
                     plan.refold()
+            torch.cuda.synchronize(dev)
             self._running_stats_moved = False
         out = self._plan(int(x.shape[0]), int(x.shape[2])).run(x)
         return out if src_device == dev else out.to(src_device)
