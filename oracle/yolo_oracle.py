@@ -124,7 +124,8 @@ def _round_bf16(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def forward(state_dict, blocks, params, x, return_layers=False, training=False, emulate_bf16=False):
+def forward(state_dict, blocks, params, x, return_layers=False, training=False, emulate_bf16=False,
+            sum_dtype=None):
     """yolo_v3.forward with is_training=False (yolo_v3.py:449-496).  ``state_dict``
     uses the reference's key names (module_list.<i>.conv_<i>.weight,
     module_list.<i>.bach_norm_<i>.*).  ``x`` is a (B, C, H, H) float32 torch tensor
@@ -145,7 +146,11 @@ def forward(state_dict, blocks, params, x, return_layers=False, training=False, 
     bias, LeakyReLU and the shortcut add that follows it; the convolutions in front of
     the yolo blocks keep their fp32 sums, which are decoded in fp32.  It answers one
     question for the tests: how far is a bf16 kernel from what bf16 storage alone gives.
-    The reference has no such mode (it is an fp32 program); this is a derived checker."""
+    The reference has no such mode (it is an fp32 program); this is a derived checker.
+    sum_dtype (emulate_bf16 only; default float32): the type the convolution sums are
+    accumulated in before the result is taken to float32 -- torch.float64 gives the same
+    network with nothing changed but the rounding of the sums, which is how the tests show
+    what a different summation ORDER alone does to a chain of bf16 roundings."""
     import torch
     import torch.nn.functional as F
 
@@ -176,7 +181,11 @@ def forward(state_dict, blocks, params, x, return_layers=False, training=False, 
                     bias = b.float() if b is not None else torch.zeros(w.shape[0])
                 if not reads_image:
                     w = _round_bf16(w)
-                x = F.conv2d(x, w, bias, stride=ent["stride"], padding=ent["pad"])
+                if sum_dtype is None or sum_dtype == torch.float32:
+                    x = F.conv2d(x, w, bias, stride=ent["stride"], padding=ent["pad"])
+                else:
+                    x = F.conv2d(x.to(sum_dtype), w.to(sum_dtype), bias.to(sum_dtype), stride=ent["stride"],
+                                 padding=ent["pad"]).to(torch.float32)
                 if ent["leaky"]:
                     x = F.leaky_relu(x, 0.1)
                 if nxt not in ("shortcut", "yolo"):

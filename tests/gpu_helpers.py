@@ -203,3 +203,63 @@ def record_metric(name, values):
     data[name] = values
     with open(path, "w") as fh:
         json.dump(data, fh, indent=1, sort_keys=True)
+
+
+def teacher_forced_layers(keep, outs16):
+    """Every fused conv launch of a keep_all plan on the ORACLE's activations.
+
+    outs16: the per-block outputs of the oracle with bf16 storage (emulate_bf16=True) for
+    the same input the plan has just run on.  For each launch the buffers it reads (sources,
+    residual operand) are overwritten with the oracle's tensors -- bf16 values, so nothing is
+    lost -- the launch runs alone, and its output is compared with the oracle's output of the
+    same fused layer.  Same bf16 operands in, so all that may differ is the order of the fp32
+    sum: an element either has the oracle's bits or sits on the neighbouring bf16 value
+    because the two fp32 sums fell on different sides of a rounding boundary.
+
+    Returns one dict per launch: block, mismatch (share of elements whose bits differ),
+    rel_l2, worst (largest |got - ref| / (2^-7 |ref| + 1e-4 rms(ref)): <= 1 means every
+    differing element is within one bf16 step), and for fp32 outputs max_rel instead."""
+    import ctypes
+    from yolo_amd import _lib
+    from yolo_amd._lib import check, lib
+    by_index = {op["index"]: op for op in keep.ops}
+
+    def ref_of(index):          # what the buffer of block `index` holds: after the fused shortcut add
+        return outs16[index + 1] if by_index[index]["res"] else outs16[index]
+
+    def put(index):
+        ref = ref_of(index).permute(0, 2, 3, 1).contiguous()
+        buf = keep.layer_output(index)
+        buf.copy_(ref.to(buf.dtype).cuda())
+
+    size = ctypes.sizeof(_lib.ConvDesc)
+    base = ctypes.addressof(keep.descs)
+    stream = _lib.current_stream_ptr(keep.device)
+    stats = []
+    for j, op in enumerate(keep.ops):
+        for bid, _, _ in op["src"]:
+            if bid != "input":
+                put(int(bid[1:]))
+        if op["res"]:
+            put(int(op["res"][1:]))
+        keep.layer_output(op["index"]).fill_(float("nan"))
+        ptr = ctypes.cast(base + j * size, ctypes.POINTER(_lib.ConvDesc))
+        check(lib.yolo_amd_conv_forward(ptr, 1, keep.zero_page.data_ptr(), stream), "conv_forward")
+        torch.cuda.synchronize()
+        got = keep.layer_output(op["index"])
+        ref = ref_of(op["index"]).permute(0, 2, 3, 1).contiguous().cuda()
+        g32 = got.float()
+        rms = float(ref.double().pow(2).mean().sqrt())
+        diff = (g32 - ref).abs()
+        ent = dict(block=op["index"], k=op["ent"]["k"], cout=op["ent"]["cout"],
+                   rel_l2=float(torch.linalg.vector_norm(diff.flatten(), dtype=torch.float64) /
+                                (torch.linalg.vector_norm(ref.flatten(), dtype=torch.float64) + 1e-30)))
+        assert bool(torch.isfinite(g32).all()), f"block {op['index']}: the launch left NaN / inf"
+        if op["fp32"]:
+            ent["max_rel"] = float((diff / (ref.abs() + 1e-3 * rms)).max())
+        else:
+            ent["mismatch"] = float((got.view(torch.int16) != ref.to(torch.bfloat16).view(torch.int16)).float().mean())
+            ent["worst"] = float((diff / (ref.abs() * 2.0 ** -7 + 1e-4 * rms)).max())
+        stats.append(ent)
+        del got, ref, g32, diff
+    return stats

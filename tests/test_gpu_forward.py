@@ -353,7 +353,7 @@ def test_forward_layers_and_output(case):
     torch.cuda.synchronize()
     assert torch.equal(det_keep, det), "buffer placement changes the result"
     worst = 0.0
-    _, outs16 = oracle_forward(sd, H, C, A, x_np, return_layers=True, emulate_bf16=True)
+    want16, outs16 = oracle_forward(sd, H, C, A, x_np, return_layers=True, emulate_bf16=True)
     for op in plan.ops:
         i = op["index"]
         ref = outs[i + 1] if op["res"] else outs[i]          # fused shortcut: compare after the add
@@ -361,10 +361,11 @@ def test_forward_layers_and_output(case):
         got = plan.layer_output(i).float().cpu().numpy()
         err = _rel_err(got, ref)
         worst = max(worst, err)
-        assert err < 0.02, f"conv block {i}: relative L2 error {err:.4f} vs the fp32 oracle"
+        assert err < FP32_ORACLE_LAYER_GATE, f"conv block {i}: relative L2 error {err:.4f} vs the fp32 oracle"
+        # ... and no further from the fp32 reference than bf16 storage alone puts the oracle
         ref16 = (outs16[i + 1] if op["res"] else outs16[i]).permute(0, 2, 3, 1).numpy()
-        err16 = _rel_err(got, ref16)
-        assert err16 < 3e-3, f"conv block {i}: relative L2 error {err16:.5f} vs the oracle with bf16 storage"
+        assert err < STORAGE_SLACK * _rel_err(ref16, ref) + 1e-3, f"conv block {i}: {err:.4f} vs {_rel_err(ref16, ref):.4f}"
+    _check_teacher_forced(plan, outs16, case["name"])
     got = det.cpu().numpy()
     want = want.numpy()
     if case["name"] in ARR:
@@ -404,18 +405,27 @@ def test_forward_416_vs_oracle_and_end_to_end(conv3, monkeypatch):
 
 
 # ------------------------------------------------------------------ the benchmark configurations
-# bf16 bar: boxes and scores within 1e-2 relative of the reference path.  Two oracles, two questions.
+# bf16 bar: boxes and scores within 1e-2 relative of the reference path.  The device path stores
+# weights and every layer's output as bf16, and a network of 75 such layers is a chaotic map at
+# the level of the last bit: two computations that differ only in the ORDER of their fp32 sums
+# part ways (a sum that falls on the other side of a rounding boundary moves an activation by
+# 2^-8, which moves the sums of the next layer, ...) until they are as far from each other as
+# either is from the fp32 result.  So "within 1e-2 of the reference" is not something a bf16
+# path can be held to element by element, and neither is "equal to another bf16 computation".
+# What IS testable, and is gated here, is that the kernels add nothing to what bf16 storage costs:
 #
-# (1) Against the oracle with the device path's storage roundings put in (bf16 folded weights,
-#     every fused layer's output rounded once to bf16, fp32 sums, fp32 detection convolutions
-#     and decode): what is left is what the KERNELS add (summation order, the hardware exp /
-#     reciprocal of the decode).  Gated: per-layer relative L2 < 3e-3 and >= 99 % of all output
-#     elements within 1e-2 relative (rel = |got - want| / (|want| + 1e-3)).
-# (2) Against the fp32 oracle (= the reference): what bf16 STORAGE costs end to end.  Gated per
-#     layer at 2e-2 relative L2 (the worst layer measures 1.5e-2) and on the median and the
-#     objectness error; the share inside 1e-2 and the bf16-vs-fp32 keep-set agreement (Jaccard
-#     index of the kept (image, box) pairs) are reported.
-# NMS rows are bit-exact given the HIP prediction.  Everything measured goes to
+# (1) Layer by layer on identical operands ("teacher forcing").  The oracle with bf16 storage
+#     (folded bf16 weights, every fused layer's output rounded once to bf16, fp32 sums, fp32
+#     detection convolutions and decode) supplies every launch's inputs; the launch's output must
+#     then carry the oracle's BITS except where the two fp32 sums straddle a rounding boundary:
+#     at most TF_MISMATCH of the elements differ, none by more than one bf16 step, relative L2
+#     below TF_REL_L2; fp32 outputs (the detection convolutions) within TF_FP32_REL.
+# (2) Free running, end to end: the device path is no further from the fp32 oracle (= the
+#     reference) than STORAGE_SLACK x the distance of the oracle with bf16 storage, layer by
+#     layer and on the share of output elements inside 1e-2 relative
+#     (rel = |got - want| / (|want| + 1e-3)); per layer at most FP32_ORACLE_LAYER_GATE.
+# NMS rows are bit-exact given the HIP prediction.  Everything measured -- including how far the
+# device path and the oracle with bf16 storage are from each other -- goes to
 # gpurun_out/parity_metrics.json (a copy is committed under profiles/).
 CONFIG_CASES = [
     # name, H, B, C, A
@@ -425,24 +435,61 @@ CONFIG_CASES = [
     ("cfg5a_320_b1", 320, 1, 80, 3),          # video latency: split reductions
     ("cfg5b_320_b1_a1c4", 320, 1, 4, 1),      # one-anchor variant
 ]
-BF16_ORACLE_LAYER_GATE = 3e-3
-BF16_ORACLE_SHARE_GATE = 0.99
+TF_MISMATCH = 0.01          # measured: at most 0.4 % of a layer's elements (the 4608-long sums), 0.025 % on average
+TF_REL_L2 = 5e-4            # measured: at most 1.3e-4
+TF_FP32_REL = 1e-3
+# |got - ref| <= TF_WORST_STEPS x (2^-7 |ref| + 1e-4 rms(ref)): one bf16 step is between 2^-8 and 2^-7 of
+# the value, and near zero the noise of a long fp32 sum (about 1e-6 of its largest partial sum) spans
+# several of the then tiny steps (measured: up to 4.0 on the 4608-long sums); a wrong tap, channel or
+# border pixel is off by about rms(ref): thousands of these units
+TF_WORST_STEPS = 8.0
+STORAGE_SLACK = 1.25
 FP32_ORACLE_LAYER_GATE = 2e-2
 
 
-def _layer_errors(keep, outs):
-    """Relative L2 error of every conv launch's output (after the fused shortcut add) against
-    the oracle's per-block outputs, computed on the GPU in float64."""
-    errs = {}
+def _check_teacher_forced(keep, outs16, what):
+    from gpu_helpers import teacher_forced_layers
+    stats = teacher_forced_layers(keep, outs16)
+    assert len(stats) == len(keep.ops)
+    bad = []
+    for st in stats:
+        where = f"conv block {st['block']}"
+        if not st["rel_l2"] < TF_REL_L2:
+            bad.append(f"{where}: relative L2 error {st['rel_l2']:.2e}")
+        if "mismatch" in st:
+            if not st["mismatch"] < TF_MISMATCH:
+                bad.append(f"{where}: {st['mismatch']:.4f} of the elements differ")
+            if not st["worst"] <= TF_WORST_STEPS:
+                bad.append(f"{where}: an element is {st['worst']:.2f} bf16 steps away")
+        elif not st["max_rel"] < TF_FP32_REL:
+            bad.append(f"{where}: fp32 output off by {st['max_rel']:.2e}")
+    bf = [st for st in stats if "mismatch" in st]
+    summary = dict(launches=len(stats), worst_mismatch_share=max(st["mismatch"] for st in bf),
+                   mean_mismatch_share=float(np.mean([st["mismatch"] for st in bf])),
+                   worst_rel_l2=max(st["rel_l2"] for st in stats),
+                   worst_distance_in_bf16_steps=max(st["worst"] for st in bf),
+                   worst_fp32_layer_rel=max((st["max_rel"] for st in stats if "max_rel" in st), default=0.0))
+    print(f"{what}: every launch on the oracle's bf16 operands: {summary}")
+    assert not bad, f"{what}, on the oracle's bf16 operands: " + "; ".join(bad[:12])
+    return summary
+
+
+def _layer_errors(keep, outs, other=None):
+    """Relative L2 distance of every conv launch's output (after the fused shortcut add) from
+    the oracle's per-block outputs `outs`, computed on the GPU in float64; with `other` (a
+    second list of per-block outputs) the distance of THAT from `outs` as well."""
+    errs, errs_other = {}, {}
     for op in keep.ops:
         i = op["index"]
-        ref = (outs[i + 1] if op["res"] else outs[i]).permute(0, 2, 3, 1).contiguous().cuda()
+        pick = (lambda o: (o[i + 1] if op["res"] else o[i]).permute(0, 2, 3, 1).contiguous().cuda())
+        ref = pick(outs)
+        den = torch.linalg.vector_norm(ref.flatten(), dtype=torch.float64) + 1e-30
         got = keep.layer_output(i).float()
-        num = torch.linalg.vector_norm((got - ref).flatten(), dtype=torch.float64)
-        den = torch.linalg.vector_norm(ref.flatten(), dtype=torch.float64)
-        errs[i] = float(num / (den + 1e-30))
+        errs[i] = float(torch.linalg.vector_norm((got - ref).flatten(), dtype=torch.float64) / den)
+        if other is not None:
+            errs_other[i] = float(torch.linalg.vector_norm((pick(other) - ref).flatten(), dtype=torch.float64) / den)
         del ref, got
-    return errs
+    return errs, errs_other
 
 
 @pytest.mark.parametrize("case", CONFIG_CASES, ids=lambda c: c[0])
@@ -488,30 +535,28 @@ def test_forward_benchmark_configurations(case):
     assert torch.equal(det_keep, det), "fused stem / fused decode change the result"
     got = det.cpu().numpy()
 
-    # (2) the fp32 oracle = the reference's arithmetic
-    want_t, outs = oracle_forward(sd, H, C, A, x_np, return_layers=True)
-    errs32 = _layer_errors(keep, outs)
+    want_t, outs = oracle_forward(sd, H, C, A, x_np, return_layers=True)                        # the reference's arithmetic
+    want16_t, outs16 = oracle_forward(sd, H, C, A, x_np, return_layers=True, emulate_bf16=True)  # + bf16 storage
+    errs32, errs16_32 = _layer_errors(keep, outs, outs16)      # device path vs fp32; bf16-storage oracle vs fp32
+    errs16, _ = _layer_errors(keep, outs16)                    # device path vs bf16-storage oracle (reported)
     del outs
-    worst32 = max(errs32.values())
     for i, err in errs32.items():
         assert err < FP32_ORACLE_LAYER_GATE, f"conv block {i}: relative L2 error {err:.4f} vs the fp32 oracle"
-    want = want_t.numpy()
-    # (1) the oracle with bf16 storage
-    want16_t, outs = oracle_forward(sd, H, C, A, x_np, return_layers=True, emulate_bf16=True)
-    errs16 = _layer_errors(keep, outs)
-    del outs, keep
-    worst16_block = max(errs16, key=errs16.get)
-    worst16 = errs16[worst16_block]
-    want16 = want16_t.numpy()
+        assert err < STORAGE_SLACK * errs16_32[i] + 1e-3, \
+            f"conv block {i}: {err:.4f} from the fp32 oracle, bf16 storage alone accounts for {errs16_32[i]:.4f}"
+    forced = _check_teacher_forced(keep, outs16, name)          # (overwrites the plan's buffers)
+    del outs16, keep
+    want, want16 = want_t.numpy(), want16_t.numpy()
 
-    def shares(ref):
-        rel = np.abs(got - ref) / (np.abs(ref) + 1e-3)
+    def shares(a, ref):
+        rel = np.abs(a - ref) / (np.abs(ref) + 1e-3)
         return rel, dict(all=float((rel <= 1e-2).mean()), boxes=float((rel[..., :4] <= 1e-2).mean()),
                          objectness=float((rel[..., 4] <= 1e-2).mean()), scores=float((rel[..., 5:] <= 1e-2).mean()))
-    rel16, share16 = shares(want16)
-    rel, share32 = shares(want)
+    rel, share32 = shares(got, want)                 # device path vs the reference
+    rel_o, share_o = shares(want16, want)            # bf16-storage oracle vs the reference
+    rel16, share16 = shares(got, want16)             # device path vs bf16-storage oracle
     obj_err = float(np.abs(got[..., 4] - want[..., 4]).max())
-    obj_err16 = float(np.abs(got[..., 4] - want16[..., 4]).max())
+    obj_err_o = float(np.abs(want16[..., 4] - want[..., 4]).max())
 
     out = filter_results(det, params)
     rows = c_filter_results(got, params["confidence"], params["nms_thesh"], C)
@@ -522,37 +567,40 @@ def test_forward_benchmark_configurations(case):
     ref_rows = c_filter_results(want, params["confidence"], params["nms_thesh"], C)
     ref16_rows = c_filter_results(want16, params["confidence"], params["nms_thesh"], C)
     ks_hip, ks_ref, ks_ref16 = keep_set(got, rows), keep_set(want, ref_rows), keep_set(want16, ref16_rows)
-    jac = len(ks_hip & ks_ref) / max(1, len(ks_hip | ks_ref))
-    jac16 = len(ks_hip & ks_ref16) / max(1, len(ks_hip | ks_ref16))
+
+    def jaccard(p, q):
+        return round(len(p & q) / max(1, len(p | q)), 5)
     w = want[..., 4]
+    summary = lambda r, sh: dict(share_within_1e2=round(sh["all"], 5), share_within_1e2_boxes=round(sh["boxes"], 5),
+                                 share_within_1e2_objectness=round(sh["objectness"], 5),
+                                 share_within_1e2_scores=round(sh["scores"], 5), median_rel=float(np.median(r)),
+                                 p99_rel=float(np.percentile(r, 99)))
     metrics = dict(H=H, B=B, C=C, A=A,
-                   vs_bf16_oracle=dict(worst_layer_rel_l2=round(worst16, 6), worst_layer_block=int(worst16_block),
-                                       share_within_1e2=round(share16["all"], 5),
-                                       share_within_1e2_boxes=round(share16["boxes"], 5),
-                                       share_within_1e2_objectness=round(share16["objectness"], 5),
-                                       share_within_1e2_scores=round(share16["scores"], 5),
-                                       median_rel=float(np.median(rel16)), p99_rel=float(np.percentile(rel16, 99)),
-                                       max_rel=float(rel16.max()), objectness_abs_err_max=obj_err16,
-                                       rows_oracle=int(ref16_rows.shape[0]), keep_set_jaccard=round(jac16, 5)),
-                   vs_fp32_oracle=dict(worst_layer_rel_l2=round(worst32, 5), share_within_1e2=round(share32["all"], 5),
-                                       share_within_1e2_boxes=round(share32["boxes"], 5),
-                                       share_within_1e2_objectness=round(share32["objectness"], 5),
-                                       median_rel=float(np.median(rel)), p99_rel=float(np.percentile(rel, 99)),
-                                       objectness_abs_err_max=obj_err, rows_oracle=int(ref_rows.shape[0]),
-                                       keep_set_jaccard=round(jac, 5)),
+                   layers_on_oracle_operands=forced,
+                   device_vs_fp32_oracle=dict(summary(rel, share32), worst_layer_rel_l2=round(max(errs32.values()), 5),
+                                              objectness_abs_err_max=obj_err, keep_set_jaccard=jaccard(ks_hip, ks_ref)),
+                   bf16_storage_oracle_vs_fp32_oracle=dict(summary(rel_o, share_o),
+                                                           worst_layer_rel_l2=round(max(errs16_32.values()), 5),
+                                                           objectness_abs_err_max=obj_err_o,
+                                                           keep_set_jaccard=jaccard(ks_ref16, ks_ref)),
+                   device_vs_bf16_storage_oracle=dict(summary(rel16, share16),
+                                                      worst_layer_rel_l2=round(max(errs16.values()), 5),
+                                                      first_layers_rel_l2=[round(errs16[op_i], 6) for op_i in sorted(errs16)[:12]],
+                                                      keep_set_jaccard=jaccard(ks_hip, ks_ref16)),
                    objectness_fp32_oracle=dict(min=float(w.min()), p01=float(np.percentile(w, 1)),
                                                median=float(np.median(w)), p99=float(np.percentile(w, 99)),
                                                max=float(w.max()),
                                                share_within_0p02_of_conf=float(
                                                    (np.abs(w - params["confidence"]) <= 0.02).mean())),
-                   rows_hip=int(rows.shape[0]),
+                   rows=dict(device=int(rows.shape[0]), fp32_oracle=int(ref_rows.shape[0]),
+                             bf16_storage_oracle=int(ref16_rows.shape[0])),
                    kernels={"/".join(map(str, k)): v for k, v in kinds.items()})
     print(f"{name}: {metrics}")
     record_metric(name, metrics)
-    assert worst16 < BF16_ORACLE_LAYER_GATE, \
-        f"conv block {worst16_block}: relative L2 error {worst16:.5f} vs the oracle with bf16 storage"
-    assert share16["all"] >= BF16_ORACLE_SHARE_GATE, \
-        f"only {share16['all']:.4f} of the output elements are within 1e-2 relative of the oracle with bf16 storage"
+    # end to end, the device path is as close to the reference as bf16 storage allows
+    assert share32["all"] >= share_o["all"] - 0.03, \
+        f"{share32['all']:.3f} of the output within 1e-2 of the reference; bf16 storage alone gives {share_o['all']:.3f}"
+    assert np.median(rel) < max(1e-2, STORAGE_SLACK * float(np.median(rel_o))) and obj_err < max(0.05, 2 * obj_err_o)
     assert np.median(rel) < 1e-2 and obj_err < 0.05
 
 

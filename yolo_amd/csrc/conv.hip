@@ -749,7 +749,11 @@ struct Conv3Args {
 // TC = channel groups of 16 per wave: 2 (workgroup = 128 channels) or 4 (256 channels: a wave
 // then issues 24 MFMAs per tap for 6 + 4 fragment reads instead of 12 for 6 + 2; the weight
 // ring grows to 96 KiB, one workgroup of eight waves per CU, up to 256 registers).
-template <int WAVES, int STG = 1, int TC = 2, int TH = P3_TS, int TW = P3_TS, int RING = 3>
+// VAR (private-ring form only; timing experiments selected with YOLO_AMD_CONV3_VAR): bit 0 = the second
+// half of the waves (4-7, the SIMD partners of 0-3) sleeps (VAR >> 4) & 15 units of 64 cycles behind every
+// chunk barrier, so that partners stop reaching their matrix bursts together; bit 1 = the second half runs
+// at a raised static priority and nobody flips priority around the bursts; bit 2 = no priority changes at all.
+template <int WAVES, int STG = 1, int TC = 2, int TH = P3_TS, int TW = P3_TS, int RING = 3, int VAR = 0>
 __global__ void __launch_bounds__(64 * WAVES)
     __attribute__((amdgpu_waves_per_eu((TC == 4 || (STG == 9 && RING == 4)) ? 2 : (WAVES == 4 ? 3 : 4),
                                        (TC == 4 || (STG == 9 && RING == 4)) ? 2 : (WAVES == 4 ? 3 : 4))))
@@ -931,6 +935,9 @@ conv3x3_patch_kernel(const Conv3Args a) {
             }
         };
         const int wfragp = slot_of<32>(r, q) * 16;
+        if constexpr ((VAR & 2) != 0) {
+            if (half) __builtin_amdgcn_s_setprio(1);
+        }
 #pragma unroll
         for (int t = 0; t < PRIV_R - 1; ++t) issue_wp(0, t, t);
         int slot0 = 0;                             // ring slot of this chunk's tap 0
@@ -962,6 +969,9 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     // has just waited for; behind the barrier nobody reads the other patch
                     // buffer any more, so the next chunk's pieces may overwrite it
                     __builtin_amdgcn_s_barrier();
+                    if constexpr ((VAR & 1) != 0) {
+                        if (half) __builtin_amdgcn_s_sleep((VAR >> 4) & 15);
+                    }
                 }
                 asm volatile("" ::: "memory");
                 if (tap < PP && more_chunks) issue_patch(chunk + 1, tap);
@@ -989,7 +999,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                 bf16x8 xf[6];
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
-                __builtin_amdgcn_s_setprio(2);
+                if constexpr ((VAR & 6) == 0) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
                 for (int tp = 0; tp < 6; ++tp) {
                     if (tp >= ntp) break;
@@ -997,7 +1007,7 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     for (int tc = 0; tc < TC; ++tc)
                         acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
                 }
-                __builtin_amdgcn_s_setprio(0);
+                if constexpr ((VAR & 6) == 0) __builtin_amdgcn_s_setprio(0);
             }
             slot0 += 9 % PRIV_R;
             if (slot0 >= PRIV_R) slot0 -= PRIV_R;
@@ -2207,8 +2217,15 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 13, 13, 4>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.waves == 8 && c.stg == 9 && env_int("YOLO_AMD_CONV3_RING", 3) == 2)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 13, 13, 2>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
-        else if (c.waves == 8 && c.stg == 9)
-            hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.waves == 8 && c.stg == 9) {
+            switch (env_int("YOLO_AMD_CONV3_VAR", 0)) {
+#define YA_P3VAR(V) case V: hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 13, 13, 3, V>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p); break
+                YA_P3VAR(0x21); YA_P3VAR(0x41); YA_P3VAR(0x81); YA_P3VAR(2); YA_P3VAR(4); YA_P3VAR(0x43);
+#undef YA_P3VAR
+                default:
+                    hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+            }
+        }
         else if (c.waves == 8 && c.stg == 3)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.waves == 8)
