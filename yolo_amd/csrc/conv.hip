@@ -749,10 +749,9 @@ struct Conv3Args {
 // TC = channel groups of 16 per wave: 2 (workgroup = 128 channels) or 4 (256 channels: a wave
 // then issues 24 MFMAs per tap for 6 + 4 fragment reads instead of 12 for 6 + 2; the weight
 // ring grows to 96 KiB, one workgroup of eight waves per CU, up to 256 registers).
-// VAR (private-ring form only; timing experiments selected with YOLO_AMD_CONV3_VAR): bit 0 = the second
-// half of the waves (4-7, the SIMD partners of 0-3) sleeps (VAR >> 4) & 15 units of 64 cycles behind every
-// chunk barrier, so that partners stop reaching their matrix bursts together; bit 1 = the second half runs
-// at a raised static priority and nobody flips priority around the bursts; bit 2 = no priority changes at all.
+// VAR (private-ring form only, YOLO_AMD_CONV3_VAR): ABLATIONS that compute garbage, for timing only -- where
+// does a tap's time go: 0x100 no weight loads, 0x200 no fragment reads (the matrix instructions run on
+// what the registers held before), 0x400 no patch loads, 0x800 no matrix instructions.
 template <int WAVES, int STG = 1, int TC = 2, int TH = P3_TS, int TW = P3_TS, int RING = 3, int VAR = 0>
 __global__ void __launch_bounds__(64 * WAVES)
     __attribute__((amdgpu_waves_per_eu((TC == 4 || (STG == 9 && RING == 4)) ? 2 : (WAVES == 4 ? 3 : 4),
@@ -935,9 +934,6 @@ conv3x3_patch_kernel(const Conv3Args a) {
             }
         };
         const int wfragp = slot_of<32>(r, q) * 16;
-        if constexpr ((VAR & 2) != 0) {
-            if (half) __builtin_amdgcn_s_setprio(1);
-        }
 #pragma unroll
         for (int t = 0; t < PRIV_R - 1; ++t) issue_wp(0, t, t);
         int slot0 = 0;                             // ring slot of this chunk's tap 0
@@ -969,45 +965,75 @@ conv3x3_patch_kernel(const Conv3Args a) {
                     // has just waited for; behind the barrier nobody reads the other patch
                     // buffer any more, so the next chunk's pieces may overwrite it
                     __builtin_amdgcn_s_barrier();
-                    if constexpr ((VAR & 1) != 0) {
-                        if (half) __builtin_amdgcn_s_sleep((VAR >> 4) & 15);
-                    }
                 }
                 asm volatile("" ::: "memory");
-                if (tap < PP && more_chunks) issue_patch(chunk + 1, tap);
-                if constexpr (OWN_RES) {
-                    if (own_res && !more_chunks && (tap == 0 || tap == 7 || tap == 8)) {
-                        const int first = tap == 0 ? 0 : (tap == 7 ? 2 : 4);
-                        res_piece(first);
-                        res_piece(first + 1);
+                // this tap's loads: a piece of the next chunk's patch (or of the residual tile), and the
+                // weights of the tap PRIV_R - 1 ahead
+                auto tap_loads = [&]() {
+                    if constexpr ((VAR & 0x400) == 0) {
+                        if (tap < PP && more_chunks) issue_patch(chunk + 1, tap);
                     }
-                }
-                {
+                    if constexpr (OWN_RES) {
+                        if (own_res && !more_chunks && (tap == 0 || tap == 7 || tap == 8)) {
+                            const int first = tap == 0 ? 0 : (tap == 7 ? 2 : 4);
+                            res_piece(first);
+                            res_piece(first + 1);
+                        }
+                    }
                     // slot of tap t of this chunk = (slot0 + t) mod PRIV_R
                     int sl = slot0 + (tap + PRIV_R - 1) % PRIV_R;
                     if (sl >= PRIV_R) sl -= PRIV_R;
-                    if (tap + PRIV_R - 1 < 9) issue_wp(chunk, tap + PRIV_R - 1, sl);
-                    else if (more_chunks) issue_wp(chunk + 1, tap + PRIV_R - 1 - 9, sl);
-                }
+                    if constexpr ((VAR & 0x100) == 0) {
+                        if (tap + PRIV_R - 1 < 9) issue_wp(chunk, tap + PRIV_R - 1, sl);
+                        else if (more_chunks) issue_wp(chunk + 1, tap + PRIV_R - 1 - 9, sl);
+                    }
+                };
+                tap_loads();
                 const int colb = ((r + kw + TW * kh) & 15) * 16 + kh * 256;
                 int cur = slot0 + tap % PRIV_R;
                 if (cur >= PRIV_R) cur -= PRIV_R;
                 const char* ws = myring + cur * PSLOT + wfragp;
                 bf16x8 wf[TC];
-#pragma unroll
-                for (int tc = 0; tc < TC; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
                 bf16x8 xf[6];
+                if constexpr ((VAR & 0x200) == 0) {
 #pragma unroll
-                for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
-                if constexpr ((VAR & 6) == 0) __builtin_amdgcn_s_setprio(2);
+                    for (int tc = 0; tc < TC; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
 #pragma unroll
-                for (int tp = 0; tp < 6; ++tp) {
-                    if (tp >= ntp) break;
+                    for (int tp = 0; tp < 6; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + tyb[tp] + colb);
+                } else {
+                    // timing ablation: operands that look like data (not constants the compiler could fold)
 #pragma unroll
-                    for (int tc = 0; tc < TC; ++tc)
-                        acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+                    for (int tc = 0; tc < TC; ++tc) {
+                        u32x4 v = u32x4{0x3f803f80u ^ (uint32_t)(lane * 0x01010101u), 0x3fa0bf90u + (uint32_t)tc,
+                                        0xbf853f33u ^ (uint32_t)(lane << 3), 0x3f4cbf19u};
+                        asm volatile("" : "+v"(v));
+                        wf[tc] = __builtin_bit_cast(bf16x8, v);
+                    }
+#pragma unroll
+                    for (int tp = 0; tp < 6; ++tp) {
+                        u32x4 v = u32x4{0x3f913f22u ^ (uint32_t)(lane * 0x00030005u), 0xbf6a3f47u + (uint32_t)tp,
+                                        0x3f0dbfa1u ^ (uint32_t)(lane << 5), 0xbf2b3f7eu};
+                        asm volatile("" : "+v"(v));
+                        xf[tp] = __builtin_bit_cast(bf16x8, v);
+                    }
                 }
-                if constexpr ((VAR & 6) == 0) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(2);
+                if constexpr ((VAR & 0x800) == 0) {
+#pragma unroll
+                    for (int tp = 0; tp < 6; ++tp) {
+                        if (tp >= ntp) break;
+#pragma unroll
+                        for (int tc = 0; tc < TC; ++tc)
+                            acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+                    }
+                } else {
+                    // keep the fragment reads alive without the matrix work
+#pragma unroll
+                    for (int tc = 0; tc < TC; ++tc) asm volatile("" ::"v"(wf[tc]));
+#pragma unroll
+                    for (int tp = 0; tp < 6; ++tp) asm volatile("" ::"v"(xf[tp]));
+                }
+                __builtin_amdgcn_s_setprio(0);
             }
             slot0 += 9 % PRIV_R;
             if (slot0 >= PRIV_R) slot0 -= PRIV_R;
@@ -2220,7 +2246,7 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         else if (c.waves == 8 && c.stg == 9) {
             switch (env_int("YOLO_AMD_CONV3_VAR", 0)) {
 #define YA_P3VAR(V) case V: hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 13, 13, 3, V>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p); break
-                YA_P3VAR(0x21); YA_P3VAR(0x41); YA_P3VAR(0x81); YA_P3VAR(2); YA_P3VAR(4); YA_P3VAR(0x43);
+                YA_P3VAR(0x100); YA_P3VAR(0x200); YA_P3VAR(0x300); YA_P3VAR(0x700); YA_P3VAR(0x800); YA_P3VAR(0x900);
 #undef YA_P3VAR
                 default:
                     hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
