@@ -238,7 +238,7 @@ def measure_traffic(argv_tail, steps=3, warmup=1, timeout_s=240):
 
 
 KERNEL_FAMILY = {"patch": "conv3x3_patch_kernel", "stem": "conv_stem_kernel", "thin": "conv3x3_thin_kernel",
-                 "first": "conv_first_kernel"}
+                 "first": "conv_first_kernel", "block": "conv_block64_kernel"}
 
 
 def kernel_pass(plan, passes):
@@ -251,7 +251,7 @@ def kernel_pass(plan, passes):
     groups = []                                   # (first desc, count, family, flops)
     j = 0
     while j < len(plan.ops):
-        n = 2 if plan.descs[j].first_layer and plan.descs[j].fuse_next else 1
+        n = 2 if plan.descs[j].fuse_next else 1
         ch = _lib.conv_choice(plan.descs[j])
         fam = KERNEL_FAMILY.get(ch["kernel"]) or \
             f"conv_igemm_kernel<{ch['bm']}, {ch['bn']}, {ch['bk']}, act {ch['act_ksteps']}>"
@@ -301,9 +301,11 @@ def write_layer_table(path, plan, layers, per_launch, scale, B, H):
         ops = plan.ops[g["first_op"]:g["first_op"] + g["n_ops"]]
         rows = [by_index[o["index"]] for o in ops]
         fl, by = sum(r["flops"] for r in rows), sum(r["bytes"] for r in rows)
-        if g["n_ops"] == 2:       # the fused stem: the first layer's output never goes to memory
+        if g["n_ops"] == 2:       # a fused pair: the first of the two layers' output never goes to memory
             inter = B * ops[0]["Ho"] * ops[0]["Wo"] * ops[0]["ent"]["cout"] * 2
             by -= 2 * inter
+            if g["family"].startswith("conv_block"):   # ... and the block's input doubles as the shortcut operand
+                by -= B * ops[1]["Ho"] * ops[1]["Wo"] * ops[1]["ent"]["cout"] * 2
         tb = max(fl / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9))
         bound = "mfma" if fl / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12) >= by / (HBM_PEAK_GBS * 1e9) else "hbm"
         us = g["ms"] * scale * 1e3
@@ -488,7 +490,8 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
         achieved = flops_per_batch / (conv_ms * 1e-3) / 1e12
-        n_convs = len(plan.ops) - (1 if getattr(plan, "fused_stem", False) else 0)
+        n_convs = len(plan.ops) - (1 if getattr(plan, "fused_stem", False) else 0) - \
+            (1 if getattr(plan, "fused_block", False) else 0)
         N = plan.N
         stack = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                  "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),

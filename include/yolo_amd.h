@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define YOLO_AMD_ABI_VERSION 6
+#define YOLO_AMD_ABI_VERSION 7
 #define YOLO_AMD_MAX_HEADS 4
 #define YOLO_AMD_MAX_ANCHORS 8
 
@@ -234,9 +234,14 @@ typedef struct {
     const yolo_amd_head_desc* decode;
     int decode_rows;      /* N_total of the prediction tensor                   */
     int decode_anchors;   /* A                                                  */
-    int fuse_next;        /* first layer only: run it together with the next    */
-                          /* descriptor (3x3 stride-2, 32 -> 64 channels) as one */
-                          /* launch; this layer's dst is then not written        */
+    int fuse_next;        /* run this layer together with the next descriptor as */
+                          /* one launch; this layer's dst is then not written.   */
+                          /* Two pairs exist: the first layer + a 3x3 stride-2   */
+                          /* 32 -> 64 layer, and a 1x1 64 -> 32 layer + a 3x3    */
+                          /* stride-1 32 -> 64 layer whose residual operand is   */
+                          /* the 1x1 layer's src0 (the network's first residual  */
+                          /* block: conv, conv, shortcut from=-3,                */
+                          /* /root/reference/yolo_v3.py:452-473)                 */
     /* Optional device scratch for a split reduction: at small batch a layer
      * with few output tiles and a long K is cut into K slices whose fp32
      * partial sums pass through this buffer (>= yolo_amd_conv_splitk_bytes,
@@ -276,6 +281,7 @@ void yolo_amd_reload_knobs(void);
 #define YOLO_AMD_KERNEL_THIN  3 /* 3x3 stride 1, 32 -> 64 channels, weights in registers */
 #define YOLO_AMD_KERNEL_PATCH 4 /* 3x3 stride 1 with the input patch reused over the taps */
 #define YOLO_AMD_KERNEL_IGEMM 5 /* im2col implicit GEMM (every other layer)            */
+#define YOLO_AMD_KERNEL_BLOCK 6 /* 1x1 64 -> 32 + 3x3 32 -> 64 + shortcut in one launch */
 typedef struct {
     int kernel;          /* YOLO_AMD_KERNEL_*                                   */
     int bm, bn, bk;      /* output pixels x output channels per workgroup; K step */

@@ -72,6 +72,29 @@ static int check_fastdiv() {
     return bad;
 }
 
+// every tile of a persistent grid's walk is visited by exactly one workgroup
+static int check_tile_walk() {
+    int bad = 0;
+    const int grids[] = {1, 2, 3, 5, 6, 7, 8, 9, 15, 16, 17, 63, 64, 100, 256, 512, 8192};
+    std::vector<int> seen;
+    for (int ntiles = 1; ntiles <= 12000; ntiles += (ntiles < 300 ? 1 : 487)) {
+        for (int G : grids) {
+            if (G > ntiles) continue;                    // the launchers size the grid min(ntiles, cap)
+            seen.assign(ntiles, 0);
+            for (int b = 0; b < G; ++b) {
+                const TileWalk w = tile_walk_of(ntiles, G, b);
+                if (w.step < 1) { ++bad; continue; }
+                for (int t = w.first; t < w.end; t += w.step) {
+                    if (t < 0 || t >= ntiles) { ++bad; break; }
+                    ++seen[t];
+                }
+            }
+            for (int t = 0; t < ntiles; ++t) bad += seen[t] != 1;
+        }
+    }
+    return bad;
+}
+
 int main() {
     int bad = 0;
     bad += check<64>(128);
@@ -79,6 +102,7 @@ int main() {
     bad += check<32>(128);
     bad += check<32>(32);
     int fd = check_fastdiv();
-    printf("layout_bad=%d fastdiv_bad=%d\n", bad, fd);
-    return (bad || fd) ? 1 : 0;
+    int tw = check_tile_walk();
+    printf("layout_bad=%d fastdiv_bad=%d tilewalk_bad=%d\n", bad, fd, tw);
+    return (bad || fd || tw) ? 1 : 0;
 }

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} is declared in yolo_amd.h but not exported"
         assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype in yolo_amd/_lib.py"
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.yolo_amd_abi_version() == 6
+    assert _lib.lib.yolo_amd_abi_version() == 7
 
 
 def test_struct_layouts_match_the_header():

@@ -252,6 +252,75 @@ def test_thin_kernel_gives_the_im2col_kernels_bits(B, H, use_res, monkeypatch):
 
 
 # stride-1 3x3 layers on 13*2^n maps can take the patch-reuse kernel
+@pytest.mark.parametrize("B,H,W", [(2, 37, 37), (1, 52, 40), (3, 8, 16), (1, 5, 3)])
+def test_first_residual_block_in_one_launch_gives_the_two_launches_bits(B, H, W):
+    """1x1 64 -> 32, 3x3 32 -> 64, shortcut from the block's input: descriptor 0 with
+    fuse_next runs the pair as one launch (conv_block64_kernel); the bits must be those of
+    the two separate launches (im2col kernel, then thin kernel), and close to the fp32
+    reference on the same bf16 operands.  Ragged tiles, tiles that hang over both edges."""
+    from gpu_helpers import conv_reference, run_conv
+    from yolo_amd import _lib
+    from yolo_amd._lib import ConvDesc, check, lib
+    from yolo_amd.engine import pack_conv_weights
+    r = gi.rs(case_seed(f"block64_{B}_{H}_{W}"))
+    dev = torch.device("cuda")
+    x = torch.from_numpy(r.standard_normal((B, H, W, 64)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    w1 = torch.from_numpy((r.standard_normal((32, 64, 1, 1)) * np.sqrt(2.0 / 64)).astype(np.float32))
+    b1 = torch.from_numpy(r.normal(0, 0.3, 32).astype(np.float32))
+    w3 = torch.from_numpy((r.standard_normal((64, 32, 3, 3)) * np.sqrt(2.0 / 288)).astype(np.float32))
+    b3 = torch.from_numpy(r.normal(0, 0.3, 64).astype(np.float32))
+    # run_conv works on square maps only through its H = W assumption? it takes the shape from x0
+    info1, info3 = {}, {}
+    y1 = run_conv(x, w1, b1, leaky=True, info=info1)
+    y2 = run_conv(y1, w3, b3, leaky=True, residual=x, info=info3)
+    assert info1["choice"]["kernel"] == "igemm" and info3["choice"]["kernel"] == "thin"
+
+    wp1 = pack_conv_weights(w1.permute(0, 2, 3, 1).reshape(32, 64).to(dev), 32)
+    wp3 = pack_conv_weights(w3.permute(0, 2, 3, 1).reshape(64, 288).to(dev), 64)
+    bp1, bp3 = b1.to(dev), b3.to(dev)
+    mid = torch.full((B, H, W, 32), float("nan"), dtype=torch.bfloat16, device=dev)
+    out = torch.full((B, H, W, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+    zero = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    d = (ConvDesc * 2)()
+    d[0].src0, d[0].weight, d[0].bias, d[0].dst = x.data_ptr(), wp1.data_ptr(), bp1.data_ptr(), mid.data_ptr()
+    d[0].c0, d[0].c1, d[0].up0, d[0].B, d[0].H, d[0].W = 64, 0, 0, B, H, W
+    d[0].cout, d[0].cout_pad, d[0].ksize, d[0].stride, d[0].k_pad, d[0].leaky = 32, 32, 1, 1, 64, 1
+    d[0].fuse_next = 1
+    d[1].src0, d[1].weight, d[1].bias, d[1].dst = mid.data_ptr(), wp3.data_ptr(), bp3.data_ptr(), out.data_ptr()
+    d[1].residual = x.data_ptr()
+    d[1].c0, d[1].c1, d[1].up0, d[1].B, d[1].H, d[1].W = 32, 0, 0, B, H, W
+    d[1].cout, d[1].cout_pad, d[1].ksize, d[1].stride, d[1].k_pad, d[1].leaky = 64, 64, 3, 1, 288, 1
+    assert _lib.conv_choice(d[0])["kernel"] == "block"
+    for _ in range(2):                       # twice: the second launch must write the same bits
+        out.fill_(float("nan"))
+        check(lib.yolo_amd_conv_forward(d, 2, zero.data_ptr(), _lib.current_stream_ptr(dev)), "fused block")
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int16), y2.view(torch.int16)), "fused block differs from the two launches"
+    assert bool(torch.isnan(mid.float()).all()), "the 1x1 layer's output was written although the pair is fused"
+    want = conv_reference(conv_reference(x, w1, b1).to(torch.bfloat16).cuda(), w3, b3, residual=x)
+    torch.testing.assert_close(out.float().cpu(), want, rtol=1.0 / 128, atol=1.0 / 128)
+    # a pair the kernel is not built for is refused, not mis-run
+    d[1].residual = mid.data_ptr()
+    assert lib.yolo_amd_conv_forward(d, 2, zero.data_ptr(), _lib.current_stream_ptr(dev)) < 0
+    assert b"shortcut operand" in lib.yolo_amd_last_error()
+
+
+def test_a_plan_with_the_fused_block_gives_the_default_plans_bits(monkeypatch):
+    """YOLO_AMD_BLOCK=1: the plan runs the network's first residual block as one launch (off
+    by default: measured slower).  Same prediction tensor, bit for bit, as the default plan."""
+    from gpu_helpers import build_model
+    x = torch.from_numpy(gi.images(33, 3, 160)).cuda()
+    model, _, _ = build_model(160)
+    want = model(x).clone()
+    assert not model._plan(3, 160).fused_block
+    monkeypatch.setenv("YOLO_AMD_BLOCK", "1")
+    model.refold()                                     # new plans
+    got = model(x)
+    plan = model._plan(3, 160)
+    assert plan.fused_block and sum(int(d.fuse_next) for d in plan.descs) == 2      # the stem and the block
+    assert torch.equal(got, want)
+
+
 PATCH_CASES = [
     # name, B, H, cin, cout, leaky, residual, fp32_out
     ("p3_c32_n128_short_k", 1, 13, 32, 128, True, False, False),

@@ -91,7 +91,7 @@ class ConvChoice(ctypes.Structure):
 
 
 KERNEL_FIRST, KERNEL_STEM, KERNEL_THIN, KERNEL_PATCH, KERNEL_IGEMM = 1, 2, 3, 4, 5
-KERNEL_NAMES = {1: "first", 2: "stem", 3: "thin", 4: "patch", 5: "igemm"}
+KERNEL_NAMES = {1: "first", 2: "stem", 3: "thin", 4: "patch", 5: "igemm", 6: "block"}
 
 
 # name -> (restype, argtypes); every symbol include/yolo_amd.h declares
@@ -150,7 +150,7 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    want = 6
+    want = 7
     got = lib.yolo_amd_abi_version()
     if got != want:
         raise ImportError(f"{LIB_PATH} has ABI version {got}, the Python side expects {want}")

@@ -1281,6 +1281,10 @@ conv3x3_patch_kernel(const Conv3Args a) {
     }
 }
 
+__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
+    return tile_walk_of(ntiles, (int)gridDim.x, (int)blockIdx.x);
+}
+
 // ---------------------------------------------------------------- first layer
 // Network input is NCHW fp32 with at most 3 channels, so K = 9*Cin <= 32 is a
 // single MFMA step: D[channel][pixel] = W[channel][k] * X[k][pixel] with
@@ -1401,11 +1405,12 @@ conv_first_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                 __builtin_amdgcn_raw_buffer_store_b64(u32x2{0u, 0u}, rd, (int)(0xFFFFFF00u + 16u * u), 0, 0);
         }
     };
-    if ((int)blockIdx.x >= ntiles) return;
-    const int step = gridDim.x, last = ntiles - 1;
-    fetch(blockIdx.x, stage);
+    const TileWalk tw = tile_walk(ntiles);
+    if (tw.first >= tw.end) return;
+    const int step = tw.step, last = tw.end - 1;
+    fetch(tw.first, stage);
     dummy_stores();
-    for (int tile = blockIdx.x; tile < ntiles; tile += step) {
+    for (int tile = tw.first; tile < tw.end; tile += step) {
         const int b = tile / per_image, t2 = tile - b * per_image;
         const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
         __syncthreads();                                   // previous tile's gathers are done
@@ -1598,10 +1603,11 @@ conv_stem_kernel(const StemArgs a) {
             stage[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o, 0, 0);
         }
     };
-    if ((int)blockIdx.x >= ntiles) return;
-    const int step = gridDim.x, last = ntiles - 1;
-    fetch(blockIdx.x);
-    for (int tile = blockIdx.x; tile < ntiles; tile += step) {
+    const TileWalk tw = tile_walk(ntiles);
+    if (tw.first >= tw.end) return;
+    const int step = tw.step, last = tw.end - 1;
+    fetch(tw.first);
+    for (int tile = tw.first; tile < tw.end; tile += step) {
         const int b = tile / per_image, t2 = tile - b * per_image;
         const int tyi = t2 / a.tiles_x, txi = t2 - tyi * a.tiles_x;
         const int oy0 = tyi * STEM_TY, ox0 = txi * STEM_TX;
@@ -1782,12 +1788,13 @@ conv3x3_thin_kernel(const ThinArgs a) {
             lds_dma16(p, lds + buf * THIN_PATCH + (w + 4 * i) * 1024);
         }
     };
-    if ((int)blockIdx.x >= ntiles) return;
-    const int step = gridDim.x;
-    issue_patch(blockIdx.x, 0);
+    const TileWalk tw = tile_walk(ntiles);
+    if (tw.first >= tw.end) return;
+    const int step = tw.step;
+    issue_patch(tw.first, 0);
     int buf = 0;
     const int cq = q * 4;
-    for (int t = blockIdx.x; t < ntiles; t += step, buf ^= 1) {
+    for (int t = tw.first; t < tw.end; t += step, buf ^= 1) {
         const int b = t / per_image, t2 = t - b * per_image;
         const int oy0 = (t2 / a.tiles_x) * THIN_TY, ox0 = (t2 % a.tiles_x) * THIN_TX;
         auto pix = [&](int slot) -> long long {
@@ -1797,7 +1804,7 @@ conv3x3_thin_kernel(const ThinArgs a) {
         wait_vmcnt<0>();                               // this tile's patch (and the stores of the last tile)
         __builtin_amdgcn_s_barrier();                  // ... everyone's; the output tile region is free again
         asm volatile("" ::: "memory");
-        const bool more = t + step < ntiles;
+        const bool more = t + step < tw.end;
         if (a.res) {
             // residual tile first (awaited first), then the next tile's patch
             constexpr int NINST = THIN_TY * THIN_TX * 8 / 64;            // 16 instructions, 4 per wave
@@ -1858,6 +1865,187 @@ conv3x3_thin_kernel(const ThinArgs a) {
         }
         __syncthreads();
         tile_store<THIN_TY * THIN_TX, 64, 256>(tile, a.dst, 64, 0, pix);
+    }
+}
+
+// ---------------------------------------------------------------- first residual block in one launch
+// Block = 1x1 conv 64 -> 32, 3x3 conv 32 -> 64, shortcut from the block's input
+// (/root/reference/yolo_v3.py:452-473 over a "conv 32/1x1, conv 64/3x3, shortcut from=-3" group of
+// the cfg).  As two launches the 1x1 layer reads the 64-channel input (128 bytes per pixel), writes
+// its 32 channels, and the 3x3 layer reads those back plus the 64-channel input AGAIN as the
+// shortcut operand.  Here a persistent workgroup walks 8x16-pixel output tiles like the thin
+// kernel; per tile the 10x18-pixel patch of the 64-channel INPUT comes in once by LDS-DMA
+// (double buffered), the 1x1 layer is computed for all 180 patch pixels (27 % more than the
+// tile's own 128: the halo) into the 32-channel patch the nine taps read (zero where the 3x3
+// layer pads: outside the image the 1x1 layer's output does not exist), and the shortcut
+// operand is the centre of the input patch, already in LDS.  The 1x1 layer's output never goes
+// to memory and the block's input is read once: 402 MB instead of 732 MB at batch 32 x 208^2.
+// Same bits as the two launches: the 1x1 sums run over K-steps of 32 in order from zero, then
+// bias, LeakyReLU, ONE rounding to bf16; the 3x3 part is the thin kernel's sequence.
+//   in64  two buffers of 192 pixel slots x 128 B; the 16-byte chunk c of slot s sits at
+//         position c ^ ((s >> 1) & 7): the 16 consecutive slots a fragment read covers hit 16
+//         distinct 16-byte bank slots.  Filled by 24 LDS-DMA instructions of 8 slots each.
+//   p32   192 slots x 64 B in the thin kernel's layout (chunk q at q ^ ((s >> 2) & 3)); the
+//         output tile (16 KiB) takes its place once the taps are done.
+constexpr int BLK_IN = THIN_SLOTS * 128;                   // 24 KiB per input patch buffer
+
+struct BlockArgs {
+    const __bf16* src;     // (B, H, W, 64): the block's input
+    const __bf16* w1;      // [2][32][32]: 1x1 weights, K-tile major
+    const float* b1;
+    const __bf16* w3;      // [9][64][32]
+    const float* b3;
+    __bf16* dst;           // (B, H, W, 64)
+    const __bf16* zero;
+    int B, H, W, leaky1, leaky3;
+    int tiles_x, tiles_y;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv_block64_kernel(const BlockArgs a) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * BLK_IN + THIN_TILE];
+    char* const p32 = lds + 2 * BLK_IN;                    // 32-channel patch, later the output tile
+    static_assert(THIN_PATCH <= THIN_TILE, "the output tile covers the 32-channel patch it replaces");
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int wpx = w & 1, wch = w >> 1;                   // 3x3 part: pixel half (4 rows), channel half (32)
+
+    // weights as MFMA A fragments, resident for the whole kernel
+    bf16x8 w3f[9][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+            w3f[tap][tc] = *reinterpret_cast<const bf16x8*>(a.w3 + ((tap * 64 + wch * 32 + tc * 16 + n) * 32 + q * 8));
+    bf16x8 w1f[2][2];                                      // [K-step][channel group of 16]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg)
+            w1f[ks][cg] = *reinterpret_cast<const bf16x8*>(a.w1 + ((ks * 32 + cg * 16 + n) * 32 + q * 8));
+    f32x4 b1v[2];
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg) b1v[cg] = *reinterpret_cast<const f32x4*>(a.b1 + cg * 16 + q * 4);
+
+    // input patch fill: instruction j (of 24) covers slots 8j..8j+7, eight lanes per pixel;
+    // wave w issues j = w, w+4, ..., w+20
+    // (packed: column | row << 8 | chunk << 16, bit 31 = unused slot, which reads the zero page)
+    uint32_t pinfo[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int sl = 8 * (w + 4 * i) + (lane >> 3);
+        const int py = sl / THIN_PC;
+        pinfo[i] = (uint32_t)(sl - py * THIN_PC) | ((uint32_t)py << 8) | ((uint32_t)((lane & 7) ^ ((sl >> 1) & 7)) << 16) |
+                   (sl < THIN_PR * THIN_PC ? 0u : 0x80000000u);
+    }
+    const int per_image = a.tiles_x * a.tiles_y, ntiles = per_image * a.B;
+    auto issue_patch = [&](int t, int buf) {
+        const int b = t / per_image, t2 = t - b * per_image;
+        const int ty = t2 / a.tiles_x, tx = t2 - ty * a.tiles_x;
+        const int y0 = ty * THIN_TY - 1, x0 = tx * THIN_TX - 1;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int iy = y0 + (int)((pinfo[i] >> 8) & 255u), ix = x0 + (int)(pinfo[i] & 255u);
+            const bool ok = (int)pinfo[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const __bf16* p = ok ? a.src + (((size_t)b * a.H + iy) * a.W + ix) * 64 + ((pinfo[i] >> 16) & 7u) * 8 : a.zero;
+            lds_dma16(p, lds + buf * BLK_IN + (w + 4 * i) * 1024);
+        }
+    };
+    const TileWalk tw = tile_walk(ntiles);
+    if (tw.first >= tw.end) return;
+    const int step = tw.step;
+    issue_patch(tw.first, 0);
+    int buf = 0;
+    const int cq = q * 4;
+    const float slope1 = a.leaky1 ? 0.1f : 1.0f;
+    for (int t = tw.first; t < tw.end; t += step, buf ^= 1) {
+        const int b = t / per_image, t2 = t - b * per_image;
+        const int oy0 = (t2 / a.tiles_x) * THIN_TY, ox0 = (t2 % a.tiles_x) * THIN_TX;
+        auto pix = [&](int slot) -> long long {
+            const int y = oy0 + slot / THIN_TX, x = ox0 + slot % THIN_TX;
+            return (y < a.H && x < a.W) ? ((long long)b * a.H + y) * a.W + x : -1;
+        };
+        wait_vmcnt<0>();                               // this tile's input patch (and the stores of the last tile)
+        __builtin_amdgcn_s_barrier();                  // ... everyone's; the last tile's output tile has been read out
+        asm volatile("" ::: "memory");
+        if (t + step < tw.end) issue_patch(t + step, buf ^ 1);
+        const char* const ib = lds + buf * BLK_IN;
+
+        // ---- the 1x1 layer on the whole patch: pixel groups w, w+4, w+8
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int sl = 16 * (w + 4 * i) + n;
+            bf16x8 xf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                xf[ks] = *reinterpret_cast<const bf16x8*>(ib + sl * 128 + (((ks * 4 + q) ^ ((sl >> 1) & 7)) << 4));
+            const int py = sl / THIN_PC, px = sl - py * THIN_PC;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            const bool inside = sl < THIN_PR * THIN_PC && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[0][cg], xf[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[1][cg], xf[1], acc, 0, 0, 0);
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[e] + b1v[cg][e];
+                    x = x > 0.f ? x : slope1 * x;
+                    pk[e] = inside ? (__bf16)x : (__bf16)0.f;
+                }
+                // channels cg*16 + 4q .. +3 of pixel slot sl: chunk 2 cg + (q >> 1), half q & 1
+                *reinterpret_cast<bf16x4*>(p32 + sl * 64 + (((cg * 2 + (q >> 1)) ^ ((sl >> 2) & 3)) << 4) + (q & 1) * 8) = pk;
+            }
+        }
+        __syncthreads();
+
+        // ---- the 3x3 layer: nine taps from the 32-channel patch
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) acc[tc][tp] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - 3 * kh;
+            bf16x8 xf[4];
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) {
+                const int sl = (wpx * 4 + tp + kh) * THIN_PC + n + kw;
+                xf[tp] = *reinterpret_cast<const bf16x8*>(p32 + sl * 64 + ((q ^ ((sl >> 2) & 3)) << 4));
+            }
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp)
+                    acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3f[tap][tc], xf[tp], acc[tc][tp], 0, 0, 0);
+        }
+        __syncthreads();                               // everyone is done with the 32-channel patch
+
+        // ---- bias, LeakyReLU, shortcut (the centre of the input patch), one rounding
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const int slot = (wpx * 4 + tp) * THIN_TX + n;
+            const int sc = (wpx * 4 + tp + 1) * THIN_PC + n + 1;          // the same pixel in the input patch
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                const int chl = wch * 32 + tc * 16 + cq;
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(a.b3 + chl);
+                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(ib + sc * 128 + (((chl >> 3) ^ ((sc >> 1) & 7)) << 4) +
+                                                                   (chl & 7) * 2);
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[tc][tp][r] + bs[r];
+                    if (a.leaky3) x = x > 0.f ? x : 0.1f * x;
+                    v[r] = x + (float)rr[r];
+                }
+                tile_put<64>(p32, slot, chl, v, false);
+            }
+        }
+        __syncthreads();
+        tile_store<THIN_TY * THIN_TX, 64, 256>(p32, a.dst, 64, 0, pix);
     }
 }
 
@@ -2069,6 +2257,17 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
     if (with_ptrs) YA_REQUIRE(d.c1 == 0 || d.src1, "conv: src1 missing");
     YA_REQUIRE(d.up0 == 0 || (d.up0 == 1 && d.ksize == 1 && d.H % 2 == 0 && d.W % 2 == 0),
                "conv: an upsampled source is supported for 1x1 convolutions only");
+    if (d.fuse_next) {
+        // the first residual block as one launch: this 1x1 layer in front of the 3x3 layer of the next
+        // descriptor (launch_block64 checks the pair)
+        YA_REQUIRE(d.ksize == 1 && d.stride == 1 && d.c0 == 64 && d.c1 == 0 && d.up0 == 0 && d.cout == 32 &&
+                       d.cout_pad == 32 && !d.dst_fp32 && !d.decode && !d.residual,
+                   "conv: fuse_next on a layer that is not the first layer needs a 1x1 stride-1 64 -> 32 layer");
+        c.kernel = YOLO_AMD_KERNEL_BLOCK;
+        c.bm = THIN_TY * THIN_TX; c.bn = 64; c.bk = 32;
+        *out = c;
+        return YA_OK;
+    }
     int BK = pick_bk(d.c0, d.c1);
     const int BN = choose_bn(d, c.M);
     // K tile 32 keeps LDS at 32 KiB per workgroup (more resident workgroups);
@@ -2204,7 +2403,8 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
 #undef YA_FIRST
         return YA_OK;
     }
-    YA_REQUIRE(c.kernel != YOLO_AMD_KERNEL_STEM, "conv: fuse_next is handled by yolo_amd_conv_forward");
+    YA_REQUIRE(c.kernel != YOLO_AMD_KERNEL_STEM && c.kernel != YOLO_AMD_KERNEL_BLOCK,
+               "conv: fuse_next is handled by yolo_amd_conv_forward");
     YA_REQUIRE(zero_page, "conv: zero page missing");
     const int K = d.ksize * d.ksize * (d.c0 + d.c1);
     if (c.kernel == YOLO_AMD_KERNEL_THIN) {
@@ -2406,6 +2606,33 @@ static int launch_stem(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc& d
     return YA_OK;
 }
 
+// descs[0] (1x1, 64 -> 32, fuse_next set) and descs[1] (3x3, 32 -> 64, shortcut from descs[0]'s
+// input) as one launch: the first residual block of the network
+static int launch_block64(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc& d1, const void* zero_page,
+                          hipStream_t stream) {
+    YA_REQUIRE(!d0.first_layer && d0.ksize == 1 && d0.stride == 1 && d0.c0 == 64 && d0.c1 == 0 && d0.up0 == 0 &&
+                   d0.cout == 32 && d0.cout_pad == 32 && d0.k_pad == 64 && !d0.residual && !d0.dst_fp32 && !d0.decode &&
+                   !d0.bn_train,
+               "conv: fuse_next on a layer that is not the first layer needs a 1x1 stride-1 64 -> 32 layer");
+    YA_REQUIRE(!d1.first_layer && d1.ksize == 3 && d1.stride == 1 && d1.c0 == 32 && d1.c1 == 0 && d1.up0 == 0 &&
+                   d1.cout == 64 && d1.cout_pad == 64 && d1.k_pad == 288 && !d1.dst_fp32 && !d1.decode && !d1.bn_train &&
+                   !d1.fuse_next && d1.B == d0.B && d1.H == d0.H && d1.W == d0.W,
+               "conv: the fused block needs a 3x3 stride-1 32 -> 64 layer behind the 1x1 layer");
+    YA_REQUIRE(d1.residual && d1.residual == d0.src0,
+               "conv: the fused block's shortcut operand must be the 1x1 layer's input");
+    YA_REQUIRE(d0.src0 && d0.weight && d0.bias && d1.weight && d1.bias && d1.dst && zero_page, "conv: null pointer");
+    YA_REQUIRE((long long)d0.B * d0.H * d0.W * 64 < (1ll << 31), "conv: tensor too large for 32-bit element offsets");
+    BlockArgs a;
+    a.src = (const __bf16*)d0.src0; a.w1 = (const __bf16*)d0.weight; a.b1 = d0.bias;
+    a.w3 = (const __bf16*)d1.weight; a.b3 = d1.bias; a.dst = (__bf16*)d1.dst; a.zero = (const __bf16*)zero_page;
+    a.B = d0.B; a.H = d0.H; a.W = d0.W; a.leaky1 = d0.leaky; a.leaky3 = d1.leaky;
+    a.tiles_x = (d0.W + THIN_TX - 1) / THIN_TX; a.tiles_y = (d0.H + THIN_TY - 1) / THIN_TY;
+    const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.B;
+    hipLaunchKernelGGL(conv_block64_kernel, dim3((unsigned)std::min<long long>(ntiles, 256 * 2)), dim3(256), 0,
+                       stream, a);
+    return YA_OK;
+}
+
 // A layer whose BatchNorm runs on batch statistics: the convolution alone into the fp32
 // scratch, then the statistics and the normalising pass of bn.hip.
 static int launch_conv_bn_train(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream) {
@@ -2431,6 +2658,10 @@ extern "C" int yolo_amd_conv_forward(const yolo_amd_conv_desc* descs, int n, con
         if (descs[i].first_layer && descs[i].fuse_next) {
             YA_REQUIRE(i + 1 < n, "conv_forward: fuse_next on the last descriptor");
             rc = launch_stem(descs[i], descs[i + 1], stream);
+            ++i;
+        } else if (descs[i].fuse_next) {
+            YA_REQUIRE(i + 1 < n, "conv_forward: fuse_next on the last descriptor");
+            rc = launch_block64(descs[i], descs[i + 1], zero_page, stream);
             ++i;
         } else if (descs[i].bn_train) {
             rc = launch_conv_bn_train(descs[i], zero_page, stream);

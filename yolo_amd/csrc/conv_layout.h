@@ -45,4 +45,22 @@ YA_HD void slot_to_row_chunk(int p, int& row, int& c) {
     c = (p % CH) ^ chunk_swizzle<BK>(row);
 }
 
+// Tile walk of a persistent grid of G workgroups over ntiles tiles, XCD-aware.  Workgroups are
+// dealt round-robin over the eight XCDs (blockIdx % 8 says which share an L2; a speed assumption,
+// never a correctness one), and neighbouring spatial tiles share halo pixels and cache lines:
+// every group of workgroups therefore takes one CONTIGUOUS eighth of the tiles and walks it
+// side by side (tile = first + i * step while < end), so that the tiles in flight on an XCD at
+// any moment are a compact run of the image and their shared lines are fetched from HBM once.
+// Every tile is visited by exactly one workgroup for any G >= 1 (checked on the host).
+struct TileWalk {
+    int first, end, step;
+};
+YA_HD TileWalk tile_walk_of(int ntiles, int G, int block) {
+    const int ng = G < 8 ? G : 8;                              // groups (a grid of fewer than eight: one workgroup each)
+    const int g = block % ng, loc = block / ng;
+    const int nb = (G - g + ng - 1) / ng;                      // workgroups in this group
+    const int lo = (int)(((long long)ntiles * g) / ng), hi = (int)(((long long)ntiles * (g + 1)) / ng);
+    return TileWalk{lo + loc, hi, nb};
+}
+
 }  // namespace yolo_amd

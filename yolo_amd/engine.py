@@ -291,6 +291,30 @@ class Plan:
                     and e1["k"] == 3 and e1["stride"] == 2 and e1["cout"] == 64 and not o1["fp32"]):
                 self.descs[0].fuse_next = 1
                 self.fused_stem = True
+        # The first residual block (1x1 64 -> 32, 3x3 32 -> 64, shortcut from the block's
+        # input) CAN run as one launch when nothing else reads the 1x1 layer's output: its 32
+        # channels then never go to memory and the block's input is read once (366 MB of HBM
+        # traffic instead of 710 MB at batch 32 x 208^2, same bits).  Measured on MI355X the
+        # one launch takes 165 us where the two take 56 + 95 us, and the benchmark loses 1.5 %
+        # with it (the fused kernel's tile is a chain of four barrier-separated phases at two
+        # waves per SIMD, and neither of the two layers it replaces was far from the HBM rate),
+        # so it is off unless YOLO_AMD_BLOCK=1; it stays in the library and under test.
+        self.fused_block = False
+        if not self.keep_all and not self.train and os.environ.get("YOLO_AMD_BLOCK", "0") == "1":
+            for j in range(len(ops) - 1):
+                o0, o1 = ops[j], ops[j + 1]
+                e0, e1 = o0["ent"], o1["ent"]
+                mid = f"L{o0['index']}"
+                readers = [op for op in ops if any(s_[0] == mid for s_ in op["src"]) or op["res"] == mid]
+                if (not o0["first"] and e0["k"] == 1 and e0["stride"] == 1 and e0["cin"] == 64 and e0["cout"] == 32
+                        and len(o0["src"]) == 1 and o0["src"][0][2] == 0 and not o0["res"] and not o0["fp32"]
+                        and readers == [o1] and o1["src"] == [(mid, 32, 0)]
+                        and e1["k"] == 3 and e1["stride"] == 1 and e1["cout"] == 64 and not o1["fp32"]
+                        and o1["res"] == o0["src"][0][0] and self.descs[j].cout_pad == 32
+                        and self.descs[j + 1].cout_pad == 64):
+                    self.descs[j].fuse_next = 1
+                    self.fused_block = True
+                    break
         # Scratch for split reductions: at small batch the deep layers have a few
         # output tiles and K up to 4608; the library cuts such a K into slices when
         # it is lent a buffer (one for all layers: they run in stream order).

@@ -260,6 +260,7 @@ class _HostCount:
         self.view = self.tensor.numpy()
         self.event = torch.cuda.Event()
         self.stream = None
+        self.recorded = False
 
     @classmethod
     def take(cls):
@@ -273,15 +274,27 @@ class _HostCount:
         hc.stream = None
         return hc
 
-    def launched(self, stream):
-        """Call right after the kernels have been queued on `stream`."""
+    def launched(self, stream, record=True):
+        """Call right after the kernels have been queued on `stream`.  record=False leaves the
+        event out (recording one costs the stream a few microseconds): for the synchronous
+        caller, who consumes the rows on the launch stream and hands the counter back only
+        after K has arrived, i.e. after the one kernel that writes to it has run."""
         self.stream = stream
-        self.event.record(stream)
+        self.recorded = bool(record)
+        if record:
+            self.event.record(stream)
 
     def give_back(self):
-        """Return the counter: to the pool if everything queued with it has run, else to
-        the list of counters whose kernels are still in flight."""
-        if self.stream is None or self.event.query():
+        """Return the counter: to the pool if the kernel that stores into it has run (K has
+        arrived, or everything queued with it is over), else to the list of counters whose
+        kernels are still in flight."""
+        if self.stream is None or self.view[0] != -1:
+            _HostCount._pool.append(self)
+            return
+        if not self.recorded:
+            self.event.record(self.stream)      # a failed wait: park it behind what is queued now
+            self.recorded = True
+        if self.event.query():
             _HostCount._pool.append(self)
         else:
             _HostCount._limbo.append(self)
@@ -315,11 +328,14 @@ class _HostCount:
         block under reads queued on that other stream."""
         cur = torch.cuda.current_stream(rows.device)
         if self.stream is not None and cur != self.stream:
+            if not self.recorded:
+                self.event.record(self.stream)
+                self.recorded = True
             cur.wait_event(self.event)
             rows.record_stream(cur)
 
 
-def _launch_filter_results(prediction, params):
+def _launch_filter_results(prediction, params, record_event=True):
     """Queue the NMS kernels on the current stream.  Returns (rows buffer, host
     count, source device), or None for an empty input."""
     pred, dev = _to_device_f32(prediction)
@@ -343,7 +359,7 @@ def _launch_filter_results(prediction, params):
                   "filter_results")
     finally:
         # also after a failed launch: some kernels may have been queued already
-        cnt.launched(stream)
+        cnt.launched(stream, record_event)
     return out, cnt, dev
 
 
@@ -360,7 +376,7 @@ def filter_results(prediction, params):
     output.shape[0]); the rows themselves are ready in stream order, like any
     other tensor a kernel has just written.
     """
-    launched = _launch_filter_results(prediction, params)
+    launched = _launch_filter_results(prediction, params, record_event=False)
     if launched is None:
         return 0
     out, cnt, dev = launched
