@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define YOLO_AMD_ABI_VERSION 7
+#define YOLO_AMD_ABI_VERSION 8
 #define YOLO_AMD_MAX_HEADS 4
 #define YOLO_AMD_MAX_ANCHORS 8
 
@@ -292,6 +292,8 @@ typedef struct {
                          /* wave stages its own channels' weights, one barrier per */
                          /* nine taps                                              */
     int k_slices;        /* > 1: split reduction + finishing launch              */
+    int patch_flat;      /* PATCH with private rings: 1 = flat patch planes (fragment */
+                         /* addresses are constants), 0 = rotated 16-slot rows      */
 } yolo_amd_conv_choice;
 int yolo_amd_conv_query(const yolo_amd_conv_desc* desc, yolo_amd_conv_choice* out);
 

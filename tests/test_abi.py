@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(raw, name), f"{name} is declared in yolo_amd.h but not exported"
         assert name in _lib.SYMBOLS, f"{name} has no ctypes prototype in yolo_amd/_lib.py"
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.lib.yolo_amd_abi_version() == 7
+    assert _lib.lib.yolo_amd_abi_version() == 8
 
 
 def test_struct_layouts_match_the_header():
@@ -75,11 +75,11 @@ def test_conv_query_reports_the_kernel_without_a_gpu():
     assert q(desc(32, 416, 3, 32, 3, 1, first=1))["kernel"] == "first"
     assert q(desc(32, 208, 32, 64, 3, 1))["kernel"] == "thin"
     c = q(desc(32, 26, 256, 512, 3, 1))
-    assert (c["kernel"], c["waves"], c["taps_per_stage"]) == ("patch", 8, 9)    # private weight rings
+    assert (c["kernel"], c["waves"], c["taps_per_stage"], c["patch_flat"]) == ("patch", 8, 9, 1)    # private weight rings, flat patch
     c = q(desc(32, 52, 128, 256, 3, 1))
-    assert (c["kernel"], c["waves"], c["taps_per_stage"]) == ("patch", 8, 9)
+    assert (c["kernel"], c["waves"], c["taps_per_stage"], c["patch_flat"]) == ("patch", 8, 9, 1)
     c = q(desc(32, 38, 256, 512, 3, 1))                                   # 608: 19 * 2^n maps take 19 x 10 tiles
-    assert (c["kernel"], c["bm"], c["taps_per_stage"]) == ("patch", 190, 9)
+    assert (c["kernel"], c["bm"], c["taps_per_stage"], c["patch_flat"]) == ("patch", 190, 9, 1)
     assert q(desc(32, 40, 256, 512, 3, 1))["kernel"] == "igemm"          # 320: no tile shape for 10 * 2^n maps
     c = q(desc(32, 52, 256, 128, 1, 1))
     assert (c["kernel"], c["bn"], c["bk"], c["act_ksteps"], c["lds_stages"]) == ("igemm", 128, 32, 2, 2)

@@ -339,9 +339,9 @@ PATCH_CASES = [
 ]
 
 
-@pytest.mark.parametrize("stg", ["1", "3", "3/256", "9", "9/256"],
+@pytest.mark.parametrize("stg", ["1", "3", "3/256", "9", "9/256", "9/flat"],
                          ids=["tap-stages", "row-stages", "row-stages-256ch", "private-weight-rings",
-                              "private-weight-rings-256ch"])
+                              "private-weight-rings-256ch", "flat-patch"])
 @pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: c[0])
 def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     from gpu_helpers import conv_reference, run_conv
@@ -350,10 +350,12 @@ def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     wide = stg.endswith("/256")
     if wide and (cout + 127) // 128 * 128 % 256:
         pytest.skip("the 256-channel tile needs the padded channel count to be a multiple of 256")
-    if H % 13 and stg not in ("1", "9"):
+    flat = "1" if stg == "9/flat" else "0"                     # the default form; "9" is the same rings on rotated patch rows
+    if H % 13 and stg not in ("1", "9") and flat == "0":
         pytest.skip("19 x 10 tiles exist with tap-deep weight stages and with private weight rings")
     set_knob(monkeypatch, "YOLO_AMD_CONV3_STG", stg[0])
     set_knob(monkeypatch, "YOLO_AMD_CONV3_TC", "4" if wide else "2")
+    set_knob(monkeypatch, "YOLO_AMD_CONV3_FLAT", flat)
     r = gi.rs(case_seed(name))
     x0 = torch.from_numpy(r.standard_normal((B, H, H, cin)).astype(np.float32)).cuda().to(torch.bfloat16)
     w = torch.from_numpy((r.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (cin * 9))).astype(np.float32))
@@ -365,8 +367,15 @@ def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     got = run_conv(x0, w, bias, leaky=leaky, residual=res, fp32_out=fp32_out, info=info).float().cpu()
     ch = info["choice"]
     assert ch["kernel"] == "patch" and ch["bn"] == (256 if wide else 128) and ch["taps_per_stage"] == int(stg[0]), ch
+    assert ch["patch_flat"] == int(flat), ch
     want = conv_reference(x0, w, bias, leaky=leaky, residual=res)
     assert torch.isfinite(got).all(), "output holds NaN/inf (unwritten elements?)"
+    if flat != "0":
+        # the flat-patch kernel adds the same products in the same order as the rotated-patch kernel with
+        # private weight rings: the same bits
+        set_knob(monkeypatch, "YOLO_AMD_CONV3_FLAT", "0")
+        rotated = run_conv(x0, w, bias, leaky=leaky, residual=res, fp32_out=fp32_out).float().cpu()
+        assert torch.equal(got, rotated), "flat-patch kernel differs from the rotated-patch kernel"
     # and the generic im2col kernel must agree with it
     set_knob(monkeypatch, "YOLO_AMD_CONV3", "0")
     generic = run_conv(x0, w, bias, leaky=leaky, residual=res, fp32_out=fp32_out).float().cpu()

@@ -87,7 +87,7 @@ class ConvChoice(ctypes.Structure):
     """yolo_amd_conv_choice of include/yolo_amd.h."""
     _fields_ = [("kernel", ctypes.c_int), ("bm", ctypes.c_int), ("bn", ctypes.c_int), ("bk", ctypes.c_int),
                 ("act_ksteps", ctypes.c_int), ("lds_stages", ctypes.c_int), ("waves", ctypes.c_int),
-                ("taps_per_stage", ctypes.c_int), ("k_slices", ctypes.c_int)]
+                ("taps_per_stage", ctypes.c_int), ("k_slices", ctypes.c_int), ("patch_flat", ctypes.c_int)]
 
 
 KERNEL_FIRST, KERNEL_STEM, KERNEL_THIN, KERNEL_PATCH, KERNEL_IGEMM = 1, 2, 3, 4, 5
@@ -150,7 +150,7 @@ def _load():
             raise ImportError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    want = 7
+    want = 8
     got = lib.yolo_amd_abi_version()
     if got != want:
         raise ImportError(f"{LIB_PATH} has ABI version {got}, the Python side expects {want}")
@@ -166,7 +166,7 @@ def conv_choice(desc):
     check(lib.yolo_amd_conv_query(ctypes.byref(desc), ctypes.byref(c)), "conv_query")
     return {"kernel": KERNEL_NAMES[c.kernel], "bm": c.bm, "bn": c.bn, "bk": c.bk, "act_ksteps": c.act_ksteps,
             "lds_stages": c.lds_stages, "waves": c.waves, "taps_per_stage": c.taps_per_stage,
-            "k_slices": c.k_slices}
+            "k_slices": c.k_slices, "patch_flat": c.patch_flat}
 
 
 def check(rc, what):

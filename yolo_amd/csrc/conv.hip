@@ -111,6 +111,23 @@ __device__ __forceinline__ void lds_dma16_sv(const __bf16* sbase, uint32_t lane_
 #pragma clang diagnostic pop
 }
 
+// The same from a raw buffer: 16 bytes per lane from (descriptor base + soff + voff) to lds_dst + 16 * lane.
+// The per-lane part is one 32-bit byte offset, the walk over a tensor goes through the scalar offset, and a
+// lane whose offset lies beyond the descriptor's size reads as zero: padding needs no zero page, no select
+// and no 64-bit address per lane.
+__device__ __forceinline__ void lds_dma16_buf(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, char* lds_dst) {
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :
+                 : "v"(voff), "s"(rsrc), "s"(soff), "s"(base)
+                 : "memory", "m0");
+#pragma clang diagnostic pop
+}
+constexpr uint32_t kRawBufferWord3 = 0x00020000u;  // untyped 32-bit raw buffer descriptor word 3
+constexpr uint32_t kBufferNowhere = 0xFFFFFF00u;   // a byte offset beyond any descriptor these kernels build
+
 // ---------------------------------------------------------------- tile epilogue through LDS
 // The accumulator layout (one pixel x 4 channels per lane) gives 8-byte stores
 // scattered over 16 rows, and a residual that is loaded just before it is
@@ -1281,6 +1298,332 @@ conv3x3_patch_kernel(const Conv3Args a) {
     }
 }
 
+// ---------------------------------------------------------------- 3x3 with patch reuse, flat patch
+// The private-ring form of the kernel above (eight waves, 128 channels, rings three taps deep, the
+// barrier-free epilogue) with ONE change of layout that takes the address arithmetic out of the tap
+// loop.  A patch plane is the (TH+2) x (TW+2) patch stored flat with pitch PW = TW + 2 slots of 16
+// bytes: slot(py, px) = py * PW + px.  The slot an output pixel (ty, tx) reads for tap (kh, kw) is then
+// slot(ty, tx) + (kh * PW + kw): a per-lane base that never changes plus a constant that goes into the
+// ds_read's offset field, so a tap is 8 fragment reads, 2 LDS-DMA instructions and 12 MFMAs with no
+// vector ALU instruction at all (the rotated 16-slot rows above need seven per tap and wave).
+// Bank conflicts: the 16 lanes of a pixel group read slots whose residues mod 16 must differ.  Along
+// a tile row consecutive pixels are consecutive slots; from the end of row ty to the start of row
+// ty' the residue steps by 1 exactly when (ty' - ty) * PW = TW (mod 16): for the 13 x 13 tile
+// (PW = 15) that is ty' = ty + 3, so the pixel groups walk the tile's rows in the order
+// 0, 3, 6, 9, 12, 2, 5, ... (RSTEP = 3; the two wrap-arounds leave a two-way conflict in two of the
+// eleven groups).  The 19 x 10 tile (PW = 12) has no such step; it keeps the natural row order and
+// two-way conflicts at every row end, and gains 4 KiB planes instead of 6 KiB ones: rings three
+// taps deep and the barrier-free epilogue fit, which the rotated layout had no room for.
+// Measured and left out: reading the fragments of tap t + 1 (the weights' and three of the six pixel groups')
+// into a second register set before the MFMAs of tap t, the weights running three taps ahead -- the schedule
+// came out as written, no spill in the loop, and every layer was 3-6 % slower (52.1 against 50.5 us on
+// 256 -> 512 @ 26x26): with four waves per SIMD the wave's own LDS latency is already hidden by the others.
+template <int TH, int TW, int PW, int RSTEP>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+conv3x3_flat_kernel(const Conv3Args a) {
+    constexpr int NPIX = TH * TW;                  // output pixels per tile
+    constexpr int NG = (NPIX + 15) / 16;           // pixel groups of 16
+    constexpr int NTP = (NG + 1) / 2;              // pixel groups per wave (upper bound)
+    constexpr int PLANE = 4096, PATCH = 4 * PLANE; // 256 slots per plane, four 16-byte planes of a 32-channel chunk
+    constexpr int PP = 2;                          // patch LDS-DMA instructions per wave and chunk
+    constexpr int PSLOT = 2048, RING = 3;          // a tap of a wave's ring: 32 channels x 64 B
+    constexpr int RING_BYTES = 8 * RING * PSLOT;
+    static_assert(PW >= TW + 2 && (TH + 2) * PW <= 256 && NTP <= 6, "tile shape not laid out for this kernel");
+    __shared__ __attribute__((aligned(1024))) char lds_all[RING_BYTES + 2 * PATCH];
+    char* const lds = lds_all;                     // patch buffers 0 and 1 first: every fragment offset fits the ds_read offset field
+    char* const wring = lds_all + 2 * PATCH;
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto stamp = [&](int i) {
+        if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + i] = (long long)wall_clock64();
+    };
+    stamp(0);
+    if (a.trace && threadIdx.x == 0)
+        a.trace[(size_t)blockIdx.x * 8 + 4] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
+                                              (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    const int cg = w & 3, half = w >> 2;           // channel group (= patch plane it fills), pixel-group half
+    const int tp0 = half * NTP;
+    const int ntp = half == 0 ? NTP : NG - NTP;
+
+    int tile;
+    {
+        const int T = a.ntiles * a.tiles_n;
+        const int q8 = T >> 3, r8 = T & 7;
+        const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + loc;
+    }
+    const int tile_n = tile % a.tiles_n, gt = tile / a.tiles_n;
+    const int n0 = tile_n * 128;
+    const int per_img = a.tiles_y * a.tiles_x;
+    const int cb = gt / per_img;
+    const int oy0 = ((gt - cb * per_img) / a.tiles_x) * TH;
+    const int ox0 = ((gt - cb * per_img) % a.tiles_x) * TW;
+
+    // slot s of the tile's pixel order -> (ty, tx): rows are visited RSTEP apart
+    auto row_of = [](int s, int& tx) {
+        const int i = s / TW;
+        tx = s - i * TW;
+        return (i * RSTEP) % TH;
+    };
+    const int r = lane & 15, q = lane >> 4;
+    int xbase[NTP];                                // byte offset of this lane's pixel in plane q, per pixel group
+#pragma unroll
+    for (int tp = 0; tp < NTP; ++tp) {
+        int tx;
+        const int ty = row_of(min((tp0 + tp) * 16 + r, NPIX - 1), tx);
+        xbase[tp] = q * PLANE + (ty * PW + tx) * 16;
+    }
+
+    const int NCH = a.C / 32;
+    // ---- patch fill: wave w fills slots [64 j, 64 j + 64) of plane cg for j = half * PP + ii, from a raw
+    // buffer over the input tensor; a slot outside the image (padding) or the patch reads beyond the buffer
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.src, 0, (int)((uint32_t)a.ntiles / (uint32_t)(a.tiles_y * a.tiles_x) * (uint32_t)(a.H * a.W) * (uint32_t)a.C * 2u),
+        (int)kRawBufferWord3);
+    uint32_t poff[PP];
+#pragma unroll
+    for (int ii = 0; ii < PP; ++ii) {
+        const int f = 64 * (half * PP + ii) + lane;
+        const int py = f / PW, px = f - py * PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        poff[ii] = (py < TH + 2 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                       ? (uint32_t)((((cb * a.H + iy) * a.W + ix) * a.C + cg * 8) * 2)
+                       : kBufferNowhere;
+    }
+    auto issue_patch = [&](int chunk, int ii) {            // ii: compile-time after unrolling
+        lds_dma16_buf(src_rs, ii == 0 ? poff[0] : poff[1], (uint32_t)chunk * 64u,
+                      lds + (chunk & 1) * PATCH + cg * PLANE + (half * PP + ii) * 1024);
+    };
+    const int cout_pad = a.tiles_n * 128;
+    const int wstep_tap = (a.C / 32) * cout_pad * 32;     // [K/32][cout_pad][32]: one tap further
+    const int wstep_chunk = cout_pad * 32;
+
+    f32x4 acc[2][NTP];
+#pragma unroll
+    for (int tc = 0; tc < 2; ++tc) {
+        const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + cg * 32 + tc * 16 + (lane >> 4) * 4);
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp) acc[tc][tp] = bs;
+    }
+
+#pragma unroll
+    for (int ii = 0; ii < PP; ++ii) issue_patch(0, ii);
+    stamp(1);
+    char* const myring = wring + w * (RING * PSLOT);
+    const bool own_res = a.res && !a.dst_fp32 && (a.Cout & 7) == 0;
+    char* const idle = lds + (NCH & 1) * PATCH;    // the patch buffer the last chunk does not read
+    auto res_at = [&](int tp) -> char* {
+        return tp < 2 ? idle + w * 2048 + tp * 1024 : myring + ((tp - 2) >> 1) * 2048 + (tp & 1) * 1024;
+    };
+    auto res_piece = [&](int tp) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int slot = (tp0 + tp) * 16 + (ln >> 2);
+        int tx;
+        const int ty = row_of(slot, tx);
+        const bool okp = tp < ntp && slot < NPIX && oy0 + ty < a.H && ox0 + tx < a.W;
+        const int ch = n0 + cg * 32 + (((ln & 3) ^ ((ln >> 4) & 3)) * 8);
+        const __bf16* src = (okp && ch + 8 <= a.Cout)
+                                ? a.res + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + ch)
+                                : a.zero;
+        lds_dma16(src, res_at(tp));
+    };
+    const uint32_t wlane = (uint32_t)(((lane >> 2) * 32 + ((lane & 3) ^ chunk_swizzle<32>(lane >> 2)) * 8) * 2);
+    const int wbase = (n0 + cg * 32) * 32;
+    auto issue_wp = [&](int chunk, int tap, int slot) {
+        const __bf16* const sb = a.wgt + (wbase + tap * wstep_tap + chunk * wstep_chunk);
+        char* const dst = myring + slot * PSLOT;
+        lds_dma16_sv<0>(sb, wlane, dst);
+        lds_dma16_sv<1024>(sb, wlane, dst);
+    };
+    const int wfragp = slot_of<32>(r, q) * 16;
+    auto mfmas = [&](const bf16x8 (&wf)[2], const bf16x8 (&xf)[6]) {
+        __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp) {
+            if (tp >= ntp) break;
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc)
+                acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto read_w = [&](bf16x8 (&wf)[2], int tap) {  // tap: compile-time
+        const char* ws = myring + (tap % RING) * PSLOT + wfragp;
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
+    };
+    auto read_x = [&](bf16x8 (&xf)[6], const char* pb, int tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + xbase[tp] + (kh * PW + kw) * 16);
+    };
+
+    // Development aid (compiled in with -DYOLO_AMD_DEV_TRACE only, active when a trace buffer is handed
+    // over): every wave adds up, over its K loop, the shader cycles between five points of a tap --
+    // [0] end of the burst -> next tap entered, [1] the wait for the tap's weights, [5] the chunk's
+    // barrier, [2] issuing the tap's LDS-DMA instructions, [3] issuing the fragment reads until they
+    // are all back, [4] the MFMA burst -- and writes the sums behind the per-workgroup stamps.  Each
+    // stamp drains the wave's LDS reads (about 40 cycles): a diagnostic build, not a timing one.
+#ifdef YOLO_AMD_DEV_TRACE
+    uint32_t seg[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+    auto tick = [&](int i) {
+        if (a.trace) {
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t tl = (uint32_t)t;
+            if (i >= 0) seg[i] += tl - tprev;
+            tprev = tl;
+        }
+    };
+#else
+    auto tick = [&](int) {};
+#endif
+    // Two chunks are unrolled (PAR = chunk & 1) so that the chunk's patch buffer, chunk & 1, is a constant
+    // in every fragment address.
+    auto chunk_body = [&](auto PARC, int chunk) {
+        constexpr int PAR = decltype(PARC)::value;
+        const char* pb = lds + PAR * PATCH;
+        const bool more_chunks = chunk + 1 < NCH;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // Loads are answered in issue order.  Younger than this tap's weights (the last loads
+            // issued two taps ago) is what the tap before issued: a patch piece during the first
+            // PP taps of a chunk that has a successor (in the last chunk two residual pieces at
+            // taps 0, 7 and 8 instead), then two weight pieces while there are taps left to fetch for.
+            {
+                const int u = tap - 1;
+                const int n_more = 2 + ((u >= 0 && u < PP) ? 1 : 0);
+                const int n_last = (u + 2 <= 8) ? 2 : 0;
+                const int n_res = n_last + ((u == 0 || u == 7) ? 2 : 0);
+                tick(0);
+                wait_vmcnt_upto(more_chunks ? n_more : (own_res ? n_res : n_last));
+            }
+            // every wave's pieces of this chunk's patch are older than the weights it has just waited
+            // for; behind the barrier nobody reads the other patch buffer any more, so the next chunk's
+            // pieces may overwrite it
+            tick(1);
+            if (tap == 0) {
+                __builtin_amdgcn_s_barrier();
+                tick(5);
+            }
+            asm volatile("" ::: "memory");
+            if (tap < PP && more_chunks) issue_patch(chunk + 1, tap);
+            if (own_res && !more_chunks && (tap == 0 || tap == 7 || tap == 8)) {
+                const int first = tap == 0 ? 0 : (tap == 7 ? 2 : 4);
+                res_piece(first);
+                res_piece(first + 1);
+            }
+            if (tap + 2 < 9) issue_wp(chunk, tap + 2, (tap + 2) % RING);
+            else if (more_chunks) issue_wp(chunk + 1, tap + 2 - 9, (tap + 2) % RING);
+            tick(2);
+            bf16x8 wf[2], xf[6];
+            read_w(wf, tap);
+            read_x(xf, pb, tap);
+            tick(3);
+            mfmas(wf, xf);
+            tick(4);
+        }
+    };
+    issue_wp(0, 0, 0);
+    issue_wp(0, 1, 1);
+    tick(-1);
+    for (int chunk = 0; chunk < NCH; chunk += 2) {
+        chunk_body(std::integral_constant<int, 0>{}, chunk);
+        if (chunk + 1 < NCH) chunk_body(std::integral_constant<int, 1>{}, chunk + 1);
+    }
+#ifdef YOLO_AMD_DEV_TRACE
+    if (a.trace && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.trace[65536 + ((size_t)blockIdx.x * 8 + w) * 8 + i] = seg[i];
+    }
+#endif
+
+    // ---- epilogue (no workgroup barrier: see the kernel above)
+    stamp(2);
+    if (!a.dst_fp32 && (a.Cout & 7) == 0) {
+        const float slope = a.leaky ? 0.1f : 1.0f;
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) {
+#pragma unroll
+            for (int tp = 0; tp < NTP; ++tp) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[tc][tp][e] = leaky_max(acc[tc][tp][e], slope);
+            }
+        }
+        // (without a residual the pieces' places still serve as the wave's staging memory: the last chunk
+        // reads patch buffer X, and every wave is past its last read of Y)
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp) {
+            if (own_res) {                   // the pieces went out in pairs, in this order
+                if (tp == 0) wait_vmcnt<4>();
+                if (tp == 2) wait_vmcnt<2>();
+                if (tp == 4) wait_vmcnt<0>();
+            }
+            if (tp >= ntp) break;
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                const int c = (tc * 2 + (q >> 1)) ^ ((r >> 2) & 3);
+                bf16x4* p = reinterpret_cast<bf16x4*>(res_at(tp) + r * 64 + c * 16 + (q & 1) * 8);
+                float v[4] = {acc[tc][tp][0], acc[tc][tp][1], acc[tc][tp][2], acc[tc][tp][3]};
+                if (own_res) {
+                    const bf16x4 rr = *p;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+                }
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[e];
+                *p = pk;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        stamp(6);
+#pragma unroll
+        for (int tp = 0; tp < NTP; ++tp) {
+            if (tp >= ntp) break;
+            const int slot = (tp0 + tp) * 16 + (lane >> 2);
+            int tx;
+            const int ty = row_of(slot, tx);
+            const int ch = n0 + cg * 32 + (((lane & 3) ^ ((lane >> 4) & 3)) * 8);
+            const bf16x8 val = *reinterpret_cast<const bf16x8*>(res_at(tp) + lane * 16);
+            if (slot < NPIX && oy0 + ty < a.H && ox0 + tx < a.W && ch + 8 <= a.Cout)
+                store_out16((__bf16*)a.dst + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + ch), val);
+        }
+        stamp(3);
+        return;
+    }
+    const int cq = q * 4;
+#pragma unroll
+    for (int tp = 0; tp < NTP; ++tp) {
+        const int p = (tp0 + tp) * 16 + r;
+        if (tp >= ntp || p >= NPIX) continue;
+        int tx;
+        const int ty = row_of(p, tx);
+        if (oy0 + ty >= a.H || ox0 + tx >= a.W) continue;
+        const size_t m = ((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
+#pragma unroll
+        for (int tc = 0; tc < 2; ++tc) {
+            const int ch = n0 + cg * 32 + tc * 16 + cq;
+            if (ch >= a.Cout) continue;
+            const size_t o = m * a.Cout + ch;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (ch + e >= a.Cout) break;
+                float x = acc[tc][tp][e];
+                if (a.leaky) x = x > 0.f ? x : 0.1f * x;
+                if (a.res) x += (float)a.res[o + e];
+                if (a.dst_fp32) ((float*)a.dst)[o + e] = x;
+                else ((__bf16*)a.dst)[o + e] = (__bf16)x;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ TileWalk tile_walk(int ntiles) {
     return tile_walk_of(ntiles, (int)gridDim.x, (int)blockIdx.x);
 }
@@ -2221,6 +2564,7 @@ struct ConvChoice {
     int waves = 4;                  // waves per workgroup
     int stg = 0;                    // patch kernel: taps per weight stage
     int th = 0, tw = 0;             // patch kernel: output tile, rows x columns
+    int flat = 0;                   // patch kernel: flat patch planes (conv3x3_flat_kernel)
     int ksteps = 0, kslices = 1;    // split reduction: K-steps (of 32) per slice, slices
     int Ho = 0, Wo = 0;
     long long M = 0;
@@ -2321,11 +2665,20 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
         (p3 == 1 || (p3 < 0 && p3_groups >= env_int("YOLO_AMD_CONV3_MIN", 128)))) {
         c.kernel = YOLO_AMD_KERNEL_PATCH;
         c.th = th; c.tw = tw;
+        // Private weight rings come with flat patch planes (conv3x3_flat_kernel: no address arithmetic in
+        // the tap loop; equal on the 13 x 13 tiles, 4-8 % faster on the 19 x 10 ones, whose planes shrink
+        // from 6 to 4 KiB: rings three taps deep and the barrier-free epilogue fit) unless
+        // YOLO_AMD_CONV3_FLAT=0 asks for the rotated 16-slot rows, a ring depth or a timing variant of the
+        // older kernel is selected, or the input is too large for the kernel's 32-bit buffer offsets.
+        const bool flat_wanted = env_int("YOLO_AMD_CONV3_FLAT", 1) != 0 && env_int("YOLO_AMD_CONV3_RING", 3) == 3 &&
+                                 env_int("YOLO_AMD_CONV3_VAR", 0) == 0 &&
+                                 (long long)d.B * d.H * d.W * d.c0 * 2 < (long long)kBufferNowhere;
         c.bm = th * tw; c.bn = 128; c.bk = 32;
         if (th != 13) {
             // the 21-row patch buffers leave room for a tap-deep weight ring only
             // (64 KiB, two workgroups per CU), or for private rings two taps deep (80 KiB)
             c.stg = env_int("YOLO_AMD_CONV3_STG", 9) == 9 ? 9 : 1; c.waves = 8;
+            c.flat = c.stg == 9 && flat_wanted;
             *out = c;
             return YA_OK;
         }
@@ -2345,6 +2698,7 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
         // (development knob; the variant stays under test)
         if (c.waves == 8 && (c.stg == 3 || c.stg == 9) && d.cout_pad % 256 == 0 && env_int("YOLO_AMD_CONV3_TC", 2) == 4)
             c.bn = 256;
+        c.flat = c.stg == 9 && c.waves == 8 && c.bn == 128 && flat_wanted;
         *out = c;
         return YA_OK;
     }
@@ -2431,7 +2785,11 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
 #ifdef YOLO_AMD_DEV_TRACE
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
 #endif
-        if (c.th == 19 && c.stg == 9)
+        if (c.flat && c.th == 19)
+            hipLaunchKernelGGL((conv3x3_flat_kernel<19, 10, 12, 1>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.flat)
+            hipLaunchKernelGGL((conv3x3_flat_kernel<13, 13, 15, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.th == 19 && c.stg == 9)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 19, 10, 2>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.th == 19)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 1, 2, 19, 10>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
@@ -2575,7 +2933,7 @@ extern "C" int yolo_amd_conv_query(const yolo_amd_conv_desc* d, yolo_amd_conv_ch
     if (rc != YA_OK) return rc;
     out->kernel = c.kernel; out->bm = c.bm; out->bn = c.bn; out->bk = c.bk;
     out->act_ksteps = c.amul; out->lds_stages = c.nstage; out->waves = c.waves;
-    out->taps_per_stage = c.stg; out->k_slices = c.kslices;
+    out->taps_per_stage = c.stg; out->k_slices = c.kslices; out->patch_flat = c.flat;
     return YA_OK;
 }
 
