@@ -255,6 +255,8 @@ def kernel_pass(plan, passes):
         ch = _lib.conv_choice(plan.descs[j])
         fam = KERNEL_FAMILY.get(ch["kernel"]) or \
             f"conv_igemm_kernel<{ch['bm']}, {ch['bn']}, {ch['bk']}, act {ch['act_ksteps']}>"
+        if ch["kernel"] == "patch" and ch["patch_flat"]:
+            fam = "conv3x3_flat_kernel"               # the patch-reuse kernel's default form (flat patch planes)
         fl = sum(2.0 * plan.B * o["Ho"] * o["Wo"] * o["ent"]["cout"] * o["ent"]["cin"] * o["ent"]["k"] ** 2
                  for o in plan.ops[j:j + n])
         groups.append((j, n, fam, fl))

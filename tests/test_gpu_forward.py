@@ -339,9 +339,9 @@ PATCH_CASES = [
 ]
 
 
-@pytest.mark.parametrize("stg", ["1", "3", "3/256", "9", "9/256", "9/flat"],
+@pytest.mark.parametrize("stg", ["1", "3", "3/256", "9", "9/256", "9/flat", "9/flat/6"],
                          ids=["tap-stages", "row-stages", "row-stages-256ch", "private-weight-rings",
-                              "private-weight-rings-256ch", "flat-patch"])
+                              "private-weight-rings-256ch", "flat-patch", "flat-patch-six-and-five-groups"])
 @pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: c[0])
 def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     from gpu_helpers import conv_reference, run_conv
@@ -350,7 +350,11 @@ def test_conv3x3_patch_kernel(case, stg, monkeypatch):
     wide = stg.endswith("/256")
     if wide and (cout + 127) // 128 * 128 % 256:
         pytest.skip("the 256-channel tile needs the padded channel count to be a multiple of 256")
-    flat = "1" if stg == "9/flat" else "0"                     # the default form; "9" is the same rings on rotated patch rows
+    flat = "1" if stg.startswith("9/flat") else "0"            # the default form; "9" is the same rings on rotated patch rows
+    if stg == "9/flat/6":
+        if H % 13:
+            pytest.skip("the 19 x 10 tile has one split of its twelve pixel groups")
+        set_knob(monkeypatch, "YOLO_AMD_CONV3_SPLIT", "6")    # waves 0-3 six pixel groups, waves 4-7 five (default: seven and four)
     if H % 13 and stg not in ("1", "9") and flat == "0":
         pytest.skip("19 x 10 tiles exist with tap-deep weight stages and with private weight rings")
     set_knob(monkeypatch, "YOLO_AMD_CONV3_STG", stg[0])

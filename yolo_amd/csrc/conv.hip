@@ -1318,17 +1318,18 @@ conv3x3_patch_kernel(const Conv3Args a) {
 // into a second register set before the MFMAs of tap t, the weights running three taps ahead -- the schedule
 // came out as written, no spill in the loop, and every layer was 3-6 % slower (52.1 against 50.5 us on
 // 256 -> 512 @ 26x26): with four waves per SIMD the wave's own LDS latency is already hidden by the others.
-template <int TH, int TW, int PW, int RSTEP>
+template <int TH, int TW, int PW, int RSTEP, int NT0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 conv3x3_flat_kernel(const Conv3Args a) {
     constexpr int NPIX = TH * TW;                  // output pixels per tile
-    constexpr int NG = (NPIX + 15) / 16;           // pixel groups of 16
-    constexpr int NTP = (NG + 1) / 2;              // pixel groups per wave (upper bound)
+    constexpr int NG = (NPIX + 15) / 16;           // pixel groups of 16: NT0 for each of waves 0-3, the rest for waves 4-7
+    constexpr int IDLE0 = NT0 - 4, IDLE1 = NG - NT0 - 4;   // KiB of the idle patch buffer a wave of either half parks residual pieces in
     constexpr int PLANE = 4096, PATCH = 4 * PLANE; // 256 slots per plane, four 16-byte planes of a 32-channel chunk
     constexpr int PP = 2;                          // patch LDS-DMA instructions per wave and chunk
     constexpr int PSLOT = 2048, RING = 3;          // a tap of a wave's ring: 32 channels x 64 B
     constexpr int RING_BYTES = 8 * RING * PSLOT;
-    static_assert(PW >= TW + 2 && (TH + 2) * PW <= 256 && NTP <= 6, "tile shape not laid out for this kernel");
+    static_assert(PW >= TW + 2 && (TH + 2) * PW <= 256 && NT0 <= 8 && IDLE1 >= 0 && 4 * (IDLE0 + IDLE1) * 1024 <= PATCH,
+                  "tile shape not laid out for this kernel");
     __shared__ __attribute__((aligned(1024))) char lds_all[RING_BYTES + 2 * PATCH];
     char* const lds = lds_all;                     // patch buffers 0 and 1 first: every fragment offset fits the ds_read offset field
     char* const wring = lds_all + 2 * PATCH;
@@ -1343,8 +1344,7 @@ conv3x3_flat_kernel(const Conv3Args a) {
         a.trace[(size_t)blockIdx.x * 8 + 4] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |
                                               (unsigned int)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     const int cg = w & 3, half = w >> 2;           // channel group (= patch plane it fills), pixel-group half
-    const int tp0 = half * NTP;
-    const int ntp = half == 0 ? NTP : NG - NTP;
+    const int tp0 = half * NT0;                    // first pixel group of this wave
 
     int tile;
     {
@@ -1367,13 +1367,6 @@ conv3x3_flat_kernel(const Conv3Args a) {
         return (i * RSTEP) % TH;
     };
     const int r = lane & 15, q = lane >> 4;
-    int xbase[NTP];                                // byte offset of this lane's pixel in plane q, per pixel group
-#pragma unroll
-    for (int tp = 0; tp < NTP; ++tp) {
-        int tx;
-        const int ty = row_of(min((tp0 + tp) * 16 + r, NPIX - 1), tx);
-        xbase[tp] = q * PLANE + (ty * PW + tx) * 16;
-    }
 
     const int NCH = a.C / 32;
     // ---- patch fill: wave w fills slots [64 j, 64 j + 64) of plane cg for j = half * PP + ii, from a raw
@@ -1398,37 +1391,11 @@ conv3x3_flat_kernel(const Conv3Args a) {
     const int cout_pad = a.tiles_n * 128;
     const int wstep_tap = (a.C / 32) * cout_pad * 32;     // [K/32][cout_pad][32]: one tap further
     const int wstep_chunk = cout_pad * 32;
-
-    f32x4 acc[2][NTP];
-#pragma unroll
-    for (int tc = 0; tc < 2; ++tc) {
-        const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + cg * 32 + tc * 16 + (lane >> 4) * 4);
-#pragma unroll
-        for (int tp = 0; tp < NTP; ++tp) acc[tc][tp] = bs;
-    }
-
 #pragma unroll
     for (int ii = 0; ii < PP; ++ii) issue_patch(0, ii);
     stamp(1);
     char* const myring = wring + w * (RING * PSLOT);
     const bool own_res = a.res && !a.dst_fp32 && (a.Cout & 7) == 0;
-    char* const idle = lds + (NCH & 1) * PATCH;    // the patch buffer the last chunk does not read
-    auto res_at = [&](int tp) -> char* {
-        return tp < 2 ? idle + w * 2048 + tp * 1024 : myring + ((tp - 2) >> 1) * 2048 + (tp & 1) * 1024;
-    };
-    auto res_piece = [&](int tp) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int slot = (tp0 + tp) * 16 + (ln >> 2);
-        int tx;
-        const int ty = row_of(slot, tx);
-        const bool okp = tp < ntp && slot < NPIX && oy0 + ty < a.H && ox0 + tx < a.W;
-        const int ch = n0 + cg * 32 + (((ln & 3) ^ ((ln >> 4) & 3)) * 8);
-        const __bf16* src = (okp && ch + 8 <= a.Cout)
-                                ? a.res + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + ch)
-                                : a.zero;
-        lds_dma16(src, res_at(tp));
-    };
     const uint32_t wlane = (uint32_t)(((lane >> 2) * 32 + ((lane & 3) ^ chunk_swizzle<32>(lane >> 2)) * 8) * 2);
     const int wbase = (n0 + cg * 32) * 32;
     auto issue_wp = [&](int chunk, int tap, int slot) {
@@ -1438,27 +1405,6 @@ conv3x3_flat_kernel(const Conv3Args a) {
         lds_dma16_sv<1024>(sb, wlane, dst);
     };
     const int wfragp = slot_of<32>(r, q) * 16;
-    auto mfmas = [&](const bf16x8 (&wf)[2], const bf16x8 (&xf)[6]) {
-        __builtin_amdgcn_s_setprio(2);
-#pragma unroll
-        for (int tp = 0; tp < NTP; ++tp) {
-            if (tp >= ntp) break;
-#pragma unroll
-            for (int tc = 0; tc < 2; ++tc)
-                acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto read_w = [&](bf16x8 (&wf)[2], int tap) {  // tap: compile-time
-        const char* ws = myring + (tap % RING) * PSLOT + wfragp;
-#pragma unroll
-        for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
-    };
-    auto read_x = [&](bf16x8 (&xf)[6], const char* pb, int tap) {
-        const int kh = tap / 3, kw = tap - 3 * kh;
-#pragma unroll
-        for (int tp = 0; tp < NTP; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + xbase[tp] + (kh * PW + kw) * 16);
-    };
 
     // Development aid (compiled in with -DYOLO_AMD_DEV_TRACE only, active when a trace buffer is handed
     // over): every wave adds up, over its K loop, the shader cycles between five points of a tap --
@@ -1482,146 +1428,206 @@ conv3x3_flat_kernel(const Conv3Args a) {
 #else
     auto tick = [&](int) {};
 #endif
-    // Two chunks are unrolled (PAR = chunk & 1) so that the chunk's patch buffer, chunk & 1, is a constant
-    // in every fragment address.
-    auto chunk_body = [&](auto PARC, int chunk) {
-        constexpr int PAR = decltype(PARC)::value;
-        const char* pb = lds + PAR * PATCH;
-        const bool more_chunks = chunk + 1 < NCH;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            // Loads are answered in issue order.  Younger than this tap's weights (the last loads
-            // issued two taps ago) is what the tap before issued: a patch piece during the first
-            // PP taps of a chunk that has a successor (in the last chunk two residual pieces at
-            // taps 0, 7 and 8 instead), then two weight pieces while there are taps left to fetch for.
-            {
-                const int u = tap - 1;
-                const int n_more = 2 + ((u >= 0 && u < PP) ? 1 : 0);
-                const int n_last = (u + 2 <= 8) ? 2 : 0;
-                const int n_res = n_last + ((u == 0 || u == 7) ? 2 : 0);
-                tick(0);
-                wait_vmcnt_upto(more_chunks ? n_more : (own_res ? n_res : n_last));
-            }
-            // every wave's pieces of this chunk's patch are older than the weights it has just waited
-            // for; behind the barrier nobody reads the other patch buffer any more, so the next chunk's
-            // pieces may overwrite it
-            tick(1);
-            if (tap == 0) {
-                __builtin_amdgcn_s_barrier();
-                tick(5);
-            }
-            asm volatile("" ::: "memory");
-            if (tap < PP && more_chunks) issue_patch(chunk + 1, tap);
-            if (own_res && !more_chunks && (tap == 0 || tap == 7 || tap == 8)) {
-                const int first = tap == 0 ? 0 : (tap == 7 ? 2 : 4);
-                res_piece(first);
-                res_piece(first + 1);
-            }
-            if (tap + 2 < 9) issue_wp(chunk, tap + 2, (tap + 2) % RING);
-            else if (more_chunks) issue_wp(chunk + 1, tap + 2 - 9, (tap + 2) % RING);
-            tick(2);
-            bf16x8 wf[2], xf[6];
-            read_w(wf, tap);
-            read_x(xf, pb, tap);
-            tick(3);
-            mfmas(wf, xf);
-            tick(4);
-        }
-    };
-    issue_wp(0, 0, 0);
-    issue_wp(0, 1, 1);
-    tick(-1);
-    for (int chunk = 0; chunk < NCH; chunk += 2) {
-        chunk_body(std::integral_constant<int, 0>{}, chunk);
-        if (chunk + 1 < NCH) chunk_body(std::integral_constant<int, 1>{}, chunk + 1);
-    }
-#ifdef YOLO_AMD_DEV_TRACE
-    if (a.trace && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) a.trace[65536 + ((size_t)blockIdx.x * 8 + w) * 8 + i] = seg[i];
-    }
-#endif
 
-    // ---- epilogue (no workgroup barrier: see the kernel above)
-    stamp(2);
-    if (!a.dst_fp32 && (a.Cout & 7) == 0) {
-        const float slope = a.leaky ? 0.1f : 1.0f;
+    // The rest of the kernel for a wave that owns NTW pixel groups (a compile-time count per half, so the
+    // tap loop has no branch): NT0 for waves 0-3, NG - NT0 for waves 4-7.
+    auto body = [&](auto NTWC) {
+        constexpr int NTW = decltype(NTWC)::value;
+        constexpr int NI = NTW - 4;                // residual pieces parked in the idle patch buffer (the rest: two ring slots)
+        static_assert(NI >= 0, "at least four pixel groups per wave");
+        int xbase[NTW];                            // byte offset of this lane's pixel in plane q, per pixel group
+#pragma unroll
+        for (int tp = 0; tp < NTW; ++tp) {
+            int tx;
+            const int ty = row_of(min((tp0 + tp) * 16 + r, NPIX - 1), tx);
+            xbase[tp] = q * PLANE + (ty * PW + tx) * 16;
+        }
+        // the accumulators start from the bias
+        f32x4 acc[2][NTW];
 #pragma unroll
         for (int tc = 0; tc < 2; ++tc) {
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n0 + cg * 32 + tc * 16 + (lane >> 4) * 4);
 #pragma unroll
-            for (int tp = 0; tp < NTP; ++tp) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[tc][tp][e] = leaky_max(acc[tc][tp][e], slope);
-            }
+            for (int tp = 0; tp < NTW; ++tp) acc[tc][tp] = bs;
         }
-        // (without a residual the pieces' places still serve as the wave's staging memory: the last chunk
-        // reads patch buffer X, and every wave is past its last read of Y)
-#pragma unroll
-        for (int tp = 0; tp < NTP; ++tp) {
-            if (own_res) {                   // the pieces went out in pairs, in this order
-                if (tp == 0) wait_vmcnt<4>();
-                if (tp == 2) wait_vmcnt<2>();
-                if (tp == 4) wait_vmcnt<0>();
-            }
-            if (tp >= ntp) break;
-#pragma unroll
-            for (int tc = 0; tc < 2; ++tc) {
-                const int c = (tc * 2 + (q >> 1)) ^ ((r >> 2) & 3);
-                bf16x4* p = reinterpret_cast<bf16x4*>(res_at(tp) + r * 64 + c * 16 + (q & 1) * 8);
-                float v[4] = {acc[tc][tp][0], acc[tc][tp][1], acc[tc][tp][2], acc[tc][tp][3]};
-                if (own_res) {
-                    const bf16x4 rr = *p;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-                }
-                bf16x4 pk;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[e];
-                *p = pk;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        stamp(6);
-#pragma unroll
-        for (int tp = 0; tp < NTP; ++tp) {
-            if (tp >= ntp) break;
-            const int slot = (tp0 + tp) * 16 + (lane >> 2);
+        // Residual pieces (1 KiB: 16 pixels x 64 B of this wave's 32 channels), fetched during the last chunk
+        // into memory nobody else reads: the first NI at tap 0 into this wave's share of the patch buffer the
+        // last chunk does not read (IDLE0 KiB for each of waves 0-3, IDLE1 KiB for each of waves 4-7), two at
+        // tap 7 and two at tap 8 into the ring slots those taps no longer fetch weights for.
+        char* const idle = lds + (NCH & 1) * PATCH + (half == 0 ? w * (IDLE0 * 1024) : 4 * IDLE0 * 1024 + (w - 4) * (IDLE1 * 1024));
+        auto res_at = [&](int tp) -> char* {
+            return tp < NI ? idle + tp * 1024 : myring + ((tp - NI) >> 1) * 2048 + ((tp - NI) & 1) * 1024;
+        };
+        auto res_piece = [&](int tp) {
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int slot = (tp0 + tp) * 16 + (ln >> 2);
             int tx;
             const int ty = row_of(slot, tx);
-            const int ch = n0 + cg * 32 + (((lane & 3) ^ ((lane >> 4) & 3)) * 8);
-            const bf16x8 val = *reinterpret_cast<const bf16x8*>(res_at(tp) + lane * 16);
-            if (slot < NPIX && oy0 + ty < a.H && ox0 + tx < a.W && ch + 8 <= a.Cout)
-                store_out16((__bf16*)a.dst + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + ch), val);
+            const bool okp = slot < NPIX && oy0 + ty < a.H && ox0 + tx < a.W;
+            const int ch = n0 + cg * 32 + (((ln & 3) ^ ((ln >> 4) & 3)) * 8);
+            const __bf16* src = (okp && ch + 8 <= a.Cout)
+                                    ? a.res + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + ch)
+                                    : a.zero;
+            lds_dma16(src, res_at(tp));
+        };
+        // Two chunks are unrolled (PAR = chunk & 1) so that the chunk's patch buffer, chunk & 1, is a constant
+        // in every fragment address.
+        auto chunk_body = [&](auto PARC, int chunk) {
+            constexpr int PAR = decltype(PARC)::value;
+            const char* pb = lds + PAR * PATCH;
+            const bool more_chunks = chunk + 1 < NCH;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                // Loads are answered in issue order.  Younger than this tap's weights (the last loads
+                // issued two taps ago) is what the tap before issued: a patch piece during the first
+                // PP taps of a chunk that has a successor (in the last chunk residual pieces at taps 0,
+                // 7 and 8 instead), then two weight pieces while there are taps left to fetch for.
+                {
+                    const int u = tap - 1;
+                    const int n_more = 2 + ((u >= 0 && u < PP) ? 1 : 0);
+                    const int n_last = (u + 2 <= 8) ? 2 : 0;
+                    const int n_res = n_last + (u == 0 ? NI : (u == 7 ? 2 : 0));
+                    tick(0);
+                    wait_vmcnt_upto(more_chunks ? n_more : (own_res ? n_res : n_last));
+                }
+                // every wave's pieces of this chunk's patch are older than the weights it has just waited
+                // for; behind the barrier nobody reads the other patch buffer any more, so the next chunk's
+                // pieces may overwrite it
+                tick(1);
+                if (tap == 0) {
+                    __builtin_amdgcn_s_barrier();
+                    tick(5);
+                }
+                asm volatile("" ::: "memory");
+                if (tap < PP && more_chunks) issue_patch(chunk + 1, tap);
+                if (own_res && !more_chunks) {
+                    if (tap == 0) {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) res_piece(i);
+                    }
+                    if (tap == 7 || tap == 8) {
+                        res_piece(NI + (tap - 7) * 2);
+                        res_piece(NI + (tap - 7) * 2 + 1);
+                    }
+                }
+                if (tap + 2 < 9) issue_wp(chunk, tap + 2, (tap + 2) % RING);
+                else if (more_chunks) issue_wp(chunk + 1, tap + 2 - 9, (tap + 2) % RING);
+                tick(2);
+                const int kh = tap / 3, kw = tap - 3 * kh;
+                const char* ws = myring + (tap % RING) * PSLOT + wfragp;
+                bf16x8 wf[2], xf[NTW];
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc) wf[tc] = *reinterpret_cast<const bf16x8*>(ws + tc * 1024);
+#pragma unroll
+                for (int tp = 0; tp < NTW; ++tp) xf[tp] = *reinterpret_cast<const bf16x8*>(pb + xbase[tp] + (kh * PW + kw) * 16);
+                tick(3);
+                __builtin_amdgcn_s_setprio(2);
+#pragma unroll
+                for (int tp = 0; tp < NTW; ++tp) {
+#pragma unroll
+                    for (int tc = 0; tc < 2; ++tc)
+                        acc[tc][tp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tc], xf[tp], acc[tc][tp], 0, 0, 0);
+                }
+                __builtin_amdgcn_s_setprio(0);
+                tick(4);
+            }
+        };
+        issue_wp(0, 0, 0);
+        issue_wp(0, 1, 1);
+        tick(-1);
+        for (int chunk = 0; chunk < NCH; chunk += 2) {
+            chunk_body(std::integral_constant<int, 0>{}, chunk);
+            if (chunk + 1 < NCH) chunk_body(std::integral_constant<int, 1>{}, chunk + 1);
         }
-        stamp(3);
-        return;
-    }
-    const int cq = q * 4;
+#ifdef YOLO_AMD_DEV_TRACE
+        if (a.trace && lane == 0) {
 #pragma unroll
-    for (int tp = 0; tp < NTP; ++tp) {
-        const int p = (tp0 + tp) * 16 + r;
-        if (tp >= ntp || p >= NPIX) continue;
-        int tx;
-        const int ty = row_of(p, tx);
-        if (oy0 + ty >= a.H || ox0 + tx >= a.W) continue;
-        const size_t m = ((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
+            for (int i = 0; i < 6; ++i) a.trace[65536 + ((size_t)blockIdx.x * 8 + w) * 8 + i] = seg[i];
+        }
+#endif
+
+        // ---- epilogue (no workgroup barrier: see the kernel above)
+        stamp(2);
+        if (!a.dst_fp32 && (a.Cout & 7) == 0) {
+            const float slope = a.leaky ? 0.1f : 1.0f;
 #pragma unroll
-        for (int tc = 0; tc < 2; ++tc) {
-            const int ch = n0 + cg * 32 + tc * 16 + cq;
-            if (ch >= a.Cout) continue;
-            const size_t o = m * a.Cout + ch;
+            for (int tc = 0; tc < 2; ++tc) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (ch + e >= a.Cout) break;
-                float x = acc[tc][tp][e];
-                if (a.leaky) x = x > 0.f ? x : 0.1f * x;
-                if (a.res) x += (float)a.res[o + e];
-                if (a.dst_fp32) ((float*)a.dst)[o + e] = x;
-                else ((__bf16*)a.dst)[o + e] = (__bf16)x;
+                for (int tp = 0; tp < NTW; ++tp) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[tc][tp][e] = leaky_max(acc[tc][tp][e], slope);
+                }
+            }
+            // (without a residual the pieces' places still serve as the wave's staging memory: every wave
+            // is past its last read of the patch buffer the last chunk does not use)
+#pragma unroll
+            for (int tp = 0; tp < NTW; ++tp) {
+                if (own_res) {                   // NI pieces went out first, then two pairs
+                    if (tp == 0) wait_vmcnt<4>();
+                    if (tp == NI) wait_vmcnt<2>();
+                    if (tp == NI + 2) wait_vmcnt<0>();
+                }
+#pragma unroll
+                for (int tc = 0; tc < 2; ++tc) {
+                    const int c = (tc * 2 + (q >> 1)) ^ ((r >> 2) & 3);
+                    bf16x4* p = reinterpret_cast<bf16x4*>(res_at(tp) + r * 64 + c * 16 + (q & 1) * 8);
+                    float v[4] = {acc[tc][tp][0], acc[tc][tp][1], acc[tc][tp][2], acc[tc][tp][3]};
+                    if (own_res) {
+                        const bf16x4 rr = *p;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+                    }
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[e];
+                    *p = pk;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            stamp(6);
+#pragma unroll
+            for (int tp = 0; tp < NTW; ++tp) {
+                const int slot = (tp0 + tp) * 16 + (lane >> 2);
+                int tx;
+                const int ty = row_of(slot, tx);
+                const int ch = n0 + cg * 32 + (((lane & 3) ^ ((lane >> 4) & 3)) * 8);
+                const bf16x8 val = *reinterpret_cast<const bf16x8*>(res_at(tp) + lane * 16);
+                if (slot < NPIX && oy0 + ty < a.H && ox0 + tx < a.W && ch + 8 <= a.Cout)
+                    store_out16((__bf16*)a.dst + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + ch), val);
+            }
+            stamp(3);
+            return;
+        }
+        const int cq = q * 4;
+#pragma unroll
+        for (int tp = 0; tp < NTW; ++tp) {
+            const int p = (tp0 + tp) * 16 + r;
+            if (p >= NPIX) continue;
+            int tx;
+            const int ty = row_of(p, tx);
+            if (oy0 + ty >= a.H || ox0 + tx >= a.W) continue;
+            const size_t m = ((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx;
+#pragma unroll
+            for (int tc = 0; tc < 2; ++tc) {
+                const int ch = n0 + cg * 32 + tc * 16 + cq;
+                if (ch >= a.Cout) continue;
+                const size_t o = m * a.Cout + ch;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ch + e >= a.Cout) break;
+                    float x = acc[tc][tp][e];
+                    if (a.leaky) x = x > 0.f ? x : 0.1f * x;
+                    if (a.res) x += (float)a.res[o + e];
+                    if (a.dst_fp32) ((float*)a.dst)[o + e] = x;
+                    else ((__bf16*)a.dst)[o + e] = (__bf16)x;
+                }
             }
         }
-    }
+    };
+    if (half == 0) body(std::integral_constant<int, NT0>{});
+    else body(std::integral_constant<int, NG - NT0>{});
 }
 
 __device__ __forceinline__ TileWalk tile_walk(int ntiles) {
@@ -1867,10 +1873,10 @@ struct StemArgs {
     int tiles_x, tiles_y;
 };
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_stem_kernel(const StemArgs a) {
     constexpr int PLANE_IN = STEM_IR * STEM_IC;
-    __shared__ __attribute__((aligned(1024))) char lds[STEM_IN_BYTES + STEM_L0_BYTES];
+    __shared__ __attribute__((aligned(1024))) char lds[STEM_IN_BYTES + STEM_L0_BYTES + (STEM_STRIPS / 4) * 256 * 8];
     uint32_t* const inwords = reinterpret_cast<uint32_t*>(lds);   // input patch: bf16 hi << 16 | bf16 lo per value
     char* const l0 = lds + STEM_IN_BYTES;                  // first-layer patch; later the output tile
     static_assert(STEM_TY * STEM_TX * 64 * 2 <= STEM_L0_BYTES, "output tile fits where the patch was");
@@ -1946,6 +1952,19 @@ conv_stem_kernel(const StemArgs a) {
             stage[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o, 0, 0);
         }
     };
+    // ---- phase B: strip i of this wave holds patch pixels p = (w + 4 i) * 16 + n; per strip and lane the
+    // word of the pixel's top-left input value and the byte offset of its 16 output bytes.  (Kept in LDS,
+    // one 8-byte read per strip: as registers the eighteen values push the 72 weight fragments of the
+    // second layer into scratch, worked out per strip they are a fifth of the strip's vector instructions.)
+    u32x2* const strip_tab = reinterpret_cast<u32x2*>(lds + STEM_IN_BYTES + STEM_L0_BYTES) + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < STEM_STRIPS / 4; ++i) {
+        const int pp = min((w + 4 * i) * 16 + n, STEM_NPIX - 1);
+        const int pr = pp / STEM_PC, pc = pp - pr * STEM_PC;
+        strip_tab[i * 256] = u32x2{(uint32_t)(pr * STEM_IC + pc),
+                                   (uint32_t)((((q * STEM_PR + pr) * 2 + (pc & 1)) * STEM_HALF + (pc >> 1)) * 16)};
+    }
+    const bool last_strip_ok = (w + 4 * (STEM_STRIPS / 4 - 1)) * 16 + n < STEM_NPIX;   // only the last strip runs over
     const TileWalk tw = tile_walk(ntiles);
     if (tw.first >= tw.end) return;
     const int step = tw.step, last = tw.end - 1;
@@ -1969,13 +1988,17 @@ conv_stem_kernel(const StemArgs a) {
         __syncthreads();
         fetch(min(tile + step, last));                     // next tile streams in meanwhile
 
-        // ---- B: first-layer pixels of the patch, 16 per strip
+        // ---- B: first-layer pixels of the patch, 16 per strip.  What a strip's lanes read and where they
+        // write does not depend on the tile (strip_tab, worked out once per kernel), so a strip is one table
+        // read, the eight gathers, eight byte permutes, six MFMAs, LeakyReLU as packed multiplies and bare
+        // maxima, four packed conversions and one 16-byte LDS write.  Pixels outside the image must read as
+        // the second layer's zero padding: tiles that reach over the image's edge zero them afterwards (same
+        // wave, same LDS addresses, so in order), instead of every strip of every tile selecting per value.
+        const int y_first = 2 * oy0 - 1, x_first = 2 * ox0 - 1;
 #pragma unroll 1
         for (int i = 0; i < STEM_STRIPS / 4; ++i) {
-            const int p = (w + 4 * i) * 16 + n;
-            const int pp = min(p, STEM_NPIX - 1);
-            const int pr = pp / STEM_PC, pc = pp - pr * STEM_PC;
-            const uint32_t* ip = inwords + pr * STEM_IC + pc;
+            const u32x2 st = strip_tab[i * 256];
+            const uint32_t* ip = inwords + st[0];
             uint32_t wv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) wv[j] = ip[offl[j]];
@@ -1993,19 +2016,28 @@ conv_stem_kernel(const StemArgs a) {
                 acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xl, acc0[m], 0, 0, 0);
                 acc0[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[m], xf, acc0[m], 0, 0, 0);
             }
-            const int y = 2 * oy0 - 1 + pr, x = 2 * ox0 - 1 + pc;
-            const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
             u32x4 pk;
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const uint32_t two = pack_bf16x2(leaky_max(acc0[m][2 * t], a.slope0),
-                                                     leaky_max(acc0[m][2 * t + 1], a.slope0));
-                    pk[2 * m + t] = inside ? two : 0u;
+                    const f32x2 v = f32x2{acc0[m][2 * t], acc0[m][2 * t + 1]};
+                    const f32x2 sv = v * f32x2{a.slope0, a.slope0};
+                    float r0, r1;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r0) : "v"(v[0]), "v"(sv[0]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(r1) : "v"(v[1]), "v"(sv[1]));
+                    pk[2 * m + t] = pack_bf16x2(r0, r1);
                 }
-            if (p < STEM_NPIX)
-                *reinterpret_cast<u32x4*>(l0 + (((q * STEM_PR + pr) * 2 + (pc & 1)) * STEM_HALF + (pc >> 1)) * 16) = pk;
+            if (i + 1 < STEM_STRIPS / 4 || last_strip_ok) *reinterpret_cast<u32x4*>(l0 + st[1]) = pk;
+        }
+        if (y_first < 0 || x_first < 0 || y_first + STEM_PR > a.H || x_first + STEM_PC > a.W) {
+#pragma unroll 1
+            for (int i = 0; i < STEM_STRIPS / 4; ++i) {
+                const u32x2 st = strip_tab[i * 256];
+                const int pr = (int)st[0] / STEM_IC, pc = (int)st[0] - pr * STEM_IC;
+                const bool outside = (unsigned)(y_first + pr) >= (unsigned)a.H || (unsigned)(x_first + pc) >= (unsigned)a.W;
+                if (outside && (i + 1 < STEM_STRIPS / 4 || last_strip_ok)) *reinterpret_cast<u32x4*>(l0 + st[1]) = u32x4{0u, 0u, 0u, 0u};
+            }
         }
         __syncthreads();
 
@@ -2786,9 +2818,11 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
 #endif
         if (c.flat && c.th == 19)
-            hipLaunchKernelGGL((conv3x3_flat_kernel<19, 10, 12, 1>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+            hipLaunchKernelGGL((conv3x3_flat_kernel<19, 10, 12, 1, 7>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+        else if (c.flat && env_int("YOLO_AMD_CONV3_SPLIT", 7) == 6)
+            hipLaunchKernelGGL((conv3x3_flat_kernel<13, 13, 15, 3, 6>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.flat)
-            hipLaunchKernelGGL((conv3x3_flat_kernel<13, 13, 15, 3>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
+            hipLaunchKernelGGL((conv3x3_flat_kernel<13, 13, 15, 3, 7>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.th == 19 && c.stg == 9)
             hipLaunchKernelGGL((conv3x3_patch_kernel<8, 9, 2, 19, 10, 2>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.th == 19)
