@@ -95,10 +95,12 @@ int run(int grid) {
     std::sort(hc.begin(), hc.end());
     const double cyc = (double)hc[grid / 2] / iters;
     const int per_simd = grid * 8 / 1024;
-    printf("%2d reads %d DMA %2d MFMA acc in %s, %d waves/SIMD: %7.1f cycles per step and wave = %6.1f per SIMD-step of all its waves "
-           "(MFMA alone %4d) -> %.2f of the MFMA rate; %.0f TFLOP/s, clock %.2f GHz\n",
-           NREAD, NDMA, NMFMA, ACC_A ? "AGPRs" : "VGPRs", per_simd, cyc, cyc, NMFMA * 16 * per_simd, NMFMA * 16.0 * per_simd / cyc,
-           (double)grid * 8 * iters * NMFMA * 16384.0 / (ms * 1e-3) / 1e12, cyc * iters / (ms * 1e-3) / 1e9);
+    // (s_memtime ticks are not shader cycles under this load -- twelve MFMAs of four waves cannot issue in fewer
+    // than 768 cycles and take 615 ticks -- so the rate comes from the HIP events alone)
+    const double tf = (double)grid * 8 * iters * NMFMA * 16384.0 / (ms * 1e-3) / 1e12;
+    printf("%2d reads %d DMA %2d MFMA per step and wave, accumulators in %s, %d waves/SIMD: %5.0f TFLOP/s = %.2f us per step "
+           "(%.0f s_memtime ticks per step and wave)\n",
+           NREAD, NDMA, NMFMA, ACC_A ? "AGPRs" : "VGPRs", per_simd, tf, ms * 1e3 / iters, cyc);
     return 0;
 }
 
