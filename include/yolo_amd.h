@@ -126,6 +126,11 @@ int yolo_amd_filter_img_class(const float* rows8, int m, float cls, float nms_th
 int yolo_amd_rescale_boxes(float* rows9, int K, const float* im_dims, int B, float height,
                            void* stream);
 
+/* Keeps `stream` busy for about `microseconds` (at most 100 000) with one idle wave.  No
+ * counterpart in the reference: the host side uses it to find HIP streams whose kernels run
+ * side by side (streams that share a hardware queue run one after the other). */
+int yolo_amd_spin(int microseconds, void* stream);
+
 /* ---------------------------------------------------------------- caller pre-processing
  * Replaces the image transforms the callers apply before model(images):
  *   LetterBoxImage_cv / LetterboxImage / letterbox_image

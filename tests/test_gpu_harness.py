@@ -14,6 +14,13 @@ from yolo_amd.cfg import default_params
 
 pytestmark = pytest.mark.gpu
 
+
+def _spin_us(us):
+    """Keep torch's current stream busy for about `us` microseconds (the library's idle-wave kernel)."""
+    from yolo_amd import _lib
+    _lib.check(_lib.lib.yolo_amd_spin(int(us), torch.cuda.current_stream().cuda_stream), "spin")
+
+
 POST = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_post.npz"))
 
 
@@ -179,7 +186,7 @@ def test_rows_are_ordered_behind_the_launch_stream_for_a_consumer_on_another_str
     lane = torch.cuda.Stream()
     for _ in range(3):
         with torch.cuda.stream(lane):
-            torch.cuda._sleep(20_000_000)                 # ~10 ms ahead of the NMS kernels
+            _spin_us(10000)                 # ~10 ms ahead of the NMS kernels
             pending = filter_results_async(pred, params)
         assert not pending.done()
         rows = pending.result()                            # on the default stream
@@ -202,7 +209,7 @@ def test_a_dropped_pending_result_keeps_its_host_counter_out_of_circulation():
     parked = len(_HostCount._limbo)
     lane = torch.cuda.Stream()
     with torch.cuda.stream(lane):
-        torch.cuda._sleep(20_000_000)
+        _spin_us(10000)
         pending = filter_results_async(pred, params)
     host = pending._host
     del pending
@@ -247,12 +254,12 @@ def test_concurrent_streams_are_two_distinct_streams_that_overlap():
     assert a.cuda_stream != b.cuda_stream
     assert concurrent_streams("cuda:0") == (a, b)
 
-    def wall(streams, spin=2_000_000):
+    def wall(streams, spin=1000):                   # microseconds
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for st in streams:
             with torch.cuda.stream(st):
-                torch.cuda._sleep(spin)
+                _spin_us(spin)
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 

@@ -14,6 +14,12 @@ from helpers import assert_bit_equal, c_filter_results
 pytestmark = pytest.mark.gpu
 
 
+def _spin_us(us):
+    """Keep torch's current stream busy for about `us` microseconds (the library's idle-wave kernel)."""
+    from yolo_amd import _lib
+    _lib.check(_lib.lib.yolo_amd_spin(int(us), torch.cuda.current_stream().cuda_stream), "spin")
+
+
 def _regular(pred, conf, nms, C):
     from yolo_amd import _lib
     from yolo_amd._lib import check, lib
@@ -84,7 +90,7 @@ def test_static_scratch_entry_point_refuses_a_second_stream_while_the_first_is_b
     torch.cuda.synchronize()
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     with torch.cuda.stream(sa):
-        torch.cuda._sleep(40_000_000)                      # keeps stream A busy for ~20 ms
+        _spin_us(20000)                      # keeps stream A busy for ~20 ms
         rc = lib.yolo_amd_filter_results_static(pred.data_ptr(), 1, 2100, 9, 4, 0.1, 0.4, rows_a.data_ptr(),
                                                 cnt_a.data_ptr(), sa.cuda_stream)
         assert rc == 0, lib.yolo_amd_last_error()

@@ -117,6 +117,7 @@ SYMBOLS = {
     "yolo_amd_filter_img_class": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                   ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "yolo_amd_spin": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     "yolo_amd_rescale_boxes": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                                ctypes.c_int, ctypes.c_float, ctypes.c_void_p]),
     "yolo_amd_preprocess_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),

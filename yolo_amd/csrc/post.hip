@@ -44,9 +44,23 @@ rescale_boxes_kernel(float* __restrict__ rows, int K, const float* __restrict__ 
     r[4] = pclamp(__fdiv_rn(__fsub_rn(r[4], py), sf), 0.0f, h);
 }
 
+// One wave that does nothing for about `ticks` ticks of the 100 MHz wall clock: occupies a stream without
+// occupying the GPU (the harness uses it to find streams that run side by side).
+__global__ void __launch_bounds__(64) spin_kernel(long long ticks) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 }  // namespace yolo_amd
 
 using namespace yolo_amd;
+
+extern "C" int yolo_amd_spin(int microseconds, void* stream_) {
+    YA_REQUIRE(microseconds >= 0 && microseconds <= 100000, "spin: %d us is outside [0, 100000]", microseconds);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, (long long)microseconds * 100);
+    YA_CHECK_HIP(hipGetLastError());
+    return YA_OK;
+}
 
 extern "C" int yolo_amd_rescale_boxes(float* rows9, int K, const float* im_dims, int B, float height,
                                       void* stream_) {

@@ -171,14 +171,13 @@ def concurrent_streams(device, n=2):
     if key in _STREAM_PAIRS:
         return _STREAM_PAIRS[key]
     with torch.cuda.device(device):
-        spin = 1_000_000                               # GPU cycles, roughly half a millisecond
+        spin_us = 500                                  # the library's idle-wave kernel, half a millisecond
 
         def wall(streams):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for st in streams:
-                with torch.cuda.stream(st):
-                    torch.cuda._sleep(spin)
+                _lib.check(_lib.lib.yolo_amd_spin(spin_us, st.cuda_stream), "spin")
             torch.cuda.synchronize()
             return time.perf_counter() - t0
 
