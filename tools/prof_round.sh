@@ -2,8 +2,8 @@
 # Round profile over the benchmark itself: kernel trace summary, then SQ counter
 # passes (one rocprofv3 run per pass), aggregated per kernel family into
 # gpurun_out/<tag>_mfma_counters.json and gpurun_out/<tag>_kernel_stats.txt.
-#   bash tools/prof_round2.sh [tag]
-TAG=${1:-round2}
+#   bash tools/prof_round.sh [tag]
+TAG=${1:-round3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
 ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-pipelined --no-traffic --no-kernel-pass --in-flight 1"

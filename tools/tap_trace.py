@@ -53,7 +53,7 @@ def main():
     print(f"{a.layer}, batch {a.batch}: {nwg} workgroups, {e0.elapsed_time(e1) * 1e3:.1f} us with the stamps in; "
           f"K loop {kloop_us.mean():.1f} us = {taps} taps of {kloop_us.mean() / taps * 1e3:.0f} ns; "
           f"{tot.mean():.0f} s_memtime ticks per tap and wave ({tot.mean() / (kloop_us.mean() / taps * 1e3):.2f} per ns)")
-    for half, nm in ((slice(0, 4), "waves 0-3 (six pixel groups)"), (slice(4, 8), "waves 4-7 (five or six)")):
+    for half, nm in ((slice(0, 4), "waves 0-3 (the larger share of the pixel groups)"), (slice(4, 8), "waves 4-7 (the smaller share)")):
         m = per_tap[:, half, :].mean(axis=(0, 1))
         print(f"  {nm}: " + "; ".join(f"{NAMES[i]} {m[i]:.0f}" for i in range(6)) + f"; sum {m.sum():.0f}")
     q = np.quantile(per_tap.reshape(-1, 6), [0.1, 0.5, 0.9], axis=0)
