@@ -10,5 +10,5 @@ git show "$REV:yolo_amd/csrc/conv.hip" > build/base/conv.hip
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wno-unused-function -I."
 /opt/rocm/bin/hipcc $FLAGS -x hip -c build/base/conv.hip -o build/base/conv.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libyolo_amd_base.so build/abi.cpp.o build/nms.hip.o \
-    build/decode.hip.o build/base/conv.o build/post.hip.o build/pre.hip.o
+    build/decode.hip.o build/base/conv.o build/bn.hip.o build/post.hip.o build/pre.hip.o
 echo built ../libyolo_amd_base.so from $REV

@@ -1973,7 +1973,11 @@ conv_stem_kernel(const StemArgs a) {
         const int b = tile / per_image, t2 = tile - b * per_image;
         const int tyi = t2 / a.tiles_x, txi = t2 - tyi * a.tiles_x;
         const int oy0 = tyi * STEM_TY, ox0 = txi * STEM_TX;
-        __syncthreads();                                   // the previous tile's output tile has been stored
+        // the previous tile's output tile has been read out of LDS by every wave (its stores to memory are
+        // not waited for: nothing here depends on them)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             if ((int)threadIdx.x + 256 * u < total) {
@@ -2176,8 +2180,12 @@ conv3x3_thin_kernel(const ThinArgs a) {
             const int y = oy0 + slot / THIN_TX, x = ox0 + slot % THIN_TX;
             return (y < a.H && x < a.W) ? ((long long)b * a.H + y) * a.W + x : -1;
         };
-        wait_vmcnt<0>();                               // this tile's patch (and the stores of the last tile)
-        __builtin_amdgcn_s_barrier();                  // ... everyone's; the output tile region is free again
+        // This tile's patch has landed (waited for in front of the last tile's stores, below; before the
+        // first tile here) -- the stores themselves are not waited for: a wait at this point would expose
+        // their whole trip to memory once per tile, and nothing depends on it.
+        if (t == tw.first) wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // everyone's patch pieces are in; the output tile region is free again
         asm volatile("" ::: "memory");
         const bool more = t + step < tw.end;
         if (a.res) {
@@ -2238,7 +2246,11 @@ conv3x3_thin_kernel(const ThinArgs a) {
                 tile_put<64>(tile, slot, chl, v, a.res != nullptr);
             }
         }
-        __syncthreads();
+        // the next tile's patch pieces (issued at the top of this tile) and the last tile's stores: both old by now
+        wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         tile_store<THIN_TY * THIN_TX, 64, 256>(tile, a.dst, 64, 0, pix);
     }
 }
