@@ -251,7 +251,7 @@ def kernel_pass(plan, passes):
     groups = []                                   # (first desc, count, family, flops)
     j = 0
     while j < len(plan.ops):
-        n = 2 if plan.descs[j].fuse_next else 1
+        n = 1 + int(plan.descs[j].fuse_next)      # a fused group is one launch (the stem: up to three layers)
         ch = _lib.conv_choice(plan.descs[j])
         fam = KERNEL_FAMILY.get(ch["kernel"]) or \
             f"conv_igemm_kernel<{ch['bm']}, {ch['bn']}, {ch['bk']}, act {ch['act_ksteps']}>"
@@ -303,9 +303,11 @@ def write_layer_table(path, plan, layers, per_launch, scale, B, H):
         ops = plan.ops[g["first_op"]:g["first_op"] + g["n_ops"]]
         rows = [by_index[o["index"]] for o in ops]
         fl, by = sum(r["flops"] for r in rows), sum(r["bytes"] for r in rows)
-        if g["n_ops"] == 2:       # a fused pair: the first of the two layers' output never goes to memory
+        if g["n_ops"] >= 2:       # a fused group: the first of the layers' output never goes to memory
             inter = B * ops[0]["Ho"] * ops[0]["Wo"] * ops[0]["ent"]["cout"] * 2
             by -= 2 * inter
+            if g["n_ops"] == 3:   # ... and the third layer takes the second one's output from LDS (it is still written)
+                by -= B * ops[1]["Ho"] * ops[1]["Wo"] * ops[1]["ent"]["cout"] * 2
             if g["family"].startswith("conv_block"):   # ... and the block's input doubles as the shortcut operand
                 by -= B * ops[1]["Ho"] * ops[1]["Wo"] * ops[1]["ent"]["cout"] * 2
         tb = max(fl / (MFMA_BF16_DENSE_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9))

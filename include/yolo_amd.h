@@ -246,7 +246,11 @@ typedef struct {
                           /* stride-1 32 -> 64 layer whose residual operand is   */
                           /* the 1x1 layer's src0 (the network's first residual  */
                           /* block: conv, conv, shortcut from=-3,                */
-                          /* /root/reference/yolo_v3.py:452-473)                 */
+                          /* /root/reference/yolo_v3.py:452-473).  On the first  */
+                          /* layer the value 2 takes the descriptor after the    */
+                          /* pair as well, a 1x1 stride-1 64 -> 32 layer on the  */
+                          /* second layer's dst: three layers in one launch, the */
+                          /* second and third layers' dst both written.          */
     /* Optional device scratch for a split reduction: at small batch a layer
      * with few output tiles and a long K is cut into K slices whose fp32
      * partial sums pass through this buffer (>= yolo_amd_conv_splitk_bytes,

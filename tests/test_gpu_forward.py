@@ -414,6 +414,64 @@ def test_first_layer():
     torch.testing.assert_close(out.float().cpu(), want, rtol=1.0 / 128, atol=1.0 / 128)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 37, 37), (1, 64, 48), (3, 9, 33), (1, 416, 416)])
+def test_stem_in_one_launch_gives_the_separate_launches_bits(B, H, W):
+    """First layer (3 -> 32), stride-2 layer (32 -> 64), 1x1 layer (64 -> 32): fuse_next = 1 on
+    the first descriptor runs the first two as one launch, fuse_next = 2 all three; both the
+    64-channel and the 32-channel output must be the bits of three separate launches.  Odd
+    sizes (tiles over both edges) and the benchmark's 416 x 416."""
+    from yolo_amd import _lib
+    from yolo_amd._lib import ConvDesc, lib, check
+    from yolo_amd.engine import pack_conv_weights
+    r = gi.rs(case_seed(f"stem_{B}_{H}_{W}"))
+    dev = torch.device("cuda")
+    x = torch.from_numpy(r.uniform(0, 1, (B, 3, H, W)).astype(np.float32)).to(dev)
+    w0 = torch.from_numpy((r.standard_normal((32, 3, 3, 3)) * 0.27).astype(np.float32))
+    w1 = torch.from_numpy((r.standard_normal((64, 32, 3, 3)) * np.sqrt(2.0 / 288)).astype(np.float32))
+    w2 = torch.from_numpy((r.standard_normal((32, 64, 1, 1)) * np.sqrt(2.0 / 64)).astype(np.float32))
+    wk0 = w0.permute(0, 2, 3, 1).reshape(32, 27).t().contiguous().to(dev)
+    wk1 = pack_conv_weights(w1.permute(0, 2, 3, 1).reshape(64, 288).to(dev), 64)
+    wk2 = pack_conv_weights(w2.permute(0, 2, 3, 1).reshape(32, 64).to(dev), 32)
+    b0, b1, b2 = (torch.from_numpy(r.normal(0, 0.3, c).astype(np.float32)).to(dev) for c in (32, 64, 32))
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    zero = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    stream = _lib.current_stream_ptr(dev)
+
+    def run(fuse):
+        l0 = torch.full((B, H, W, 32), float("nan"), dtype=torch.bfloat16, device=dev)
+        l1 = torch.full((B, Ho, Wo, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+        l2 = torch.full((B, Ho, Wo, 32), float("nan"), dtype=torch.bfloat16, device=dev)
+        d = (ConvDesc * 3)()
+        d[0].src0, d[0].weight, d[0].bias, d[0].dst = x.data_ptr(), wk0.data_ptr(), b0.data_ptr(), l0.data_ptr()
+        d[0].c0, d[0].B, d[0].H, d[0].W = 3, B, H, W
+        d[0].cout, d[0].cout_pad, d[0].ksize, d[0].stride, d[0].k_pad = 32, 32, 3, 1, 27
+        d[0].leaky, d[0].first_layer, d[0].fuse_next = 1, 1, fuse
+        d[1].src0, d[1].weight, d[1].bias, d[1].dst = l0.data_ptr(), wk1.data_ptr(), b1.data_ptr(), l1.data_ptr()
+        d[1].c0, d[1].B, d[1].H, d[1].W = 32, B, H, W
+        d[1].cout, d[1].cout_pad, d[1].ksize, d[1].stride, d[1].k_pad, d[1].leaky = 64, 64, 3, 2, 288, 1
+        d[2].src0, d[2].weight, d[2].bias, d[2].dst = l1.data_ptr(), wk2.data_ptr(), b2.data_ptr(), l2.data_ptr()
+        d[2].c0, d[2].B, d[2].H, d[2].W = 64, B, Ho, Wo
+        d[2].cout, d[2].cout_pad, d[2].ksize, d[2].stride, d[2].k_pad, d[2].leaky = 32, 32, 1, 1, 64, 1
+        check(lib.yolo_amd_conv_forward(d, 3, zero.data_ptr(), stream), f"stem, fuse_next {fuse}")
+        torch.cuda.synchronize()
+        if fuse:
+            assert bool(torch.isnan(l0.float()).all()), "the first layer's output was written although it is fused"
+        return l1, l2, d
+
+    want1, want2, _ = run(0)
+    assert not bool(torch.isnan(want2.float()).any())
+    for fuse in (1, 2):
+        got1, got2, d = run(fuse)
+        assert torch.equal(got1.view(torch.int16), want1.view(torch.int16)), f"fuse_next {fuse}: 64-channel output"
+        assert torch.equal(got2.view(torch.int16), want2.view(torch.int16)), f"fuse_next {fuse}: 32-channel output"
+    # a third layer the kernel is not built for is refused, not mis-run
+    d[2].leaky, d[2].stride = 1, 2
+    assert lib.yolo_amd_conv_forward(d, 3, zero.data_ptr(), stream) < 0
+    assert b"third layer" in lib.yolo_amd_last_error()
+    d[2].stride = 1
+    assert lib.yolo_amd_conv_forward(d, 2, zero.data_ptr(), stream) < 0      # reaches past the array
+
+
 # ------------------------------------------------------------------ whole forward
 def _rel_err(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b) + 1e-30))

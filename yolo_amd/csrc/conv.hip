@@ -1871,12 +1871,30 @@ struct StemArgs {
     int leaky1;
     uint32_t src_bytes;
     int tiles_x, tiles_y;
+    // TAIL: the 1x1 layer (64 -> 32) that reads the second layer's output
+    const __bf16* w2;      // [2][32][32] bf16 (K-tile major)
+    const float* b2;
+    __bf16* dst2;
+    int leaky2;
 };
 
+// TAIL adds a phase E: the 1x1 layer behind the second layer (64 -> 32 channels, the first
+// residual block's squeeze) is computed from the output tile while it sits in LDS, with the
+// im2col kernel's two K-steps in its order (same accumulators, same bits), and leaves through
+// the input patch's LDS (idle until the next tile).  The second layer's output is still
+// written: the block's shortcut reads it.  It saves that 1x1 layer's launch, which read the
+// 64 channels back from memory.
+constexpr int STEM_TAB_BYTES = (STEM_STRIPS / 4) * 256 * 8;
+constexpr int STEM_FIRST_BYTES = 6 * 64 * 16;              // first layer: weight fragments (hi, lo) and bias per lane
+constexpr int STEM_W2_BYTES = 2 * 32 * 32 * 2;
+
+template <bool TAIL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv_stem_kernel(const StemArgs a) {
     constexpr int PLANE_IN = STEM_IR * STEM_IC;
-    __shared__ __attribute__((aligned(1024))) char lds[STEM_IN_BYTES + STEM_L0_BYTES + (STEM_STRIPS / 4) * 256 * 8];
+    __shared__ __attribute__((aligned(1024))) char lds[STEM_IN_BYTES + STEM_L0_BYTES + STEM_TAB_BYTES + STEM_FIRST_BYTES +
+                                                       (TAIL ? STEM_W2_BYTES : 0)];
+    static_assert(STEM_TY * STEM_TX * 32 * 2 <= STEM_IN_BYTES, "the 1x1 layer's tile fits where the input patch was");
     uint32_t* const inwords = reinterpret_cast<uint32_t*>(lds);   // input patch: bf16 hi << 16 | bf16 lo per value
     char* const l0 = lds + STEM_IN_BYTES;                  // first-layer patch; later the output tile
     static_assert(STEM_TY * STEM_TX * 64 * 2 <= STEM_L0_BYTES, "output tile fits where the patch was");
@@ -1899,20 +1917,28 @@ conv_stem_kernel(const StemArgs a) {
             offl[j] = (c * STEM_IR + kh) * STEM_IC + kw;
         }
     }
-    bf16x8 wf[2], wl[2];
-    f32x4 bv[2];
+    // (weight fragments hi / lo and bias of the first layer: worked out once, parked in LDS per lane and read
+    // back at the top of every tile's phase B, so that their 24 registers are free in the other phases)
+    u32x4* const first_tab = reinterpret_cast<u32x4*>(lds + STEM_IN_BYTES + STEM_L0_BYTES + STEM_TAB_BYTES) + lane;
+    if (w == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ch = 8 * (n >> 2) + 4 * i + (n & 3);     // MFMA i, row r <-> channel 8*(r>>2) + 4*i + (r&3)
+        for (int i = 0; i < 2; ++i) {
+            const int ch = 8 * (n >> 2) + 4 * i + (n & 3);     // MFMA i, row r <-> channel 8*(r>>2) + 4*i + (r&3)
+            bf16x8 f, l;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 8 * q + j;
-            const float wv = k < K0 ? a.w0[k * 32 + ch] : 0.f;
-            wf[i][j] = (__bf16)wv;
-            wl[i][j] = (__bf16)(wv - (float)wf[i][j]);
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * q + j;
+                const float wv = k < K0 ? a.w0[k * 32 + ch] : 0.f;
+                f[j] = (__bf16)wv;
+                l[j] = (__bf16)(wv - (float)f[j]);
+            }
+            f32x4 bb;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bb[t] = a.b0[8 * q + 4 * i + t];
+            first_tab[(0 + i) * 64] = __builtin_bit_cast(u32x4, f);
+            first_tab[(2 + i) * 64] = __builtin_bit_cast(u32x4, l);
+            first_tab[(4 + i) * 64] = __builtin_bit_cast(u32x4, bb);
         }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) bv[i][t] = a.b0[8 * q + 4 * i + t];
     }
     // ---- second layer: this wave's weight fragments, all nine taps
     const int wpx = w & 1, wch = w >> 1;                   // pixel half (4 rows), channel half (32)
@@ -1928,14 +1954,13 @@ conv_stem_kernel(const StemArgs a) {
 
     // ---- input patch staging: the elements this thread loads, the same for every tile
     const int total = a.Cin * PLANE_IN;
-    int pre[8], prc[8];
+    uint32_t prc[8];                                       // channel << 24 | row << 8 | column
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int e = min((int)threadIdx.x + 256 * u, total - 1);
         const int c = e / PLANE_IN, r2 = e - c * PLANE_IN;
         const int r = r2 / STEM_IC, col = r2 - r * STEM_IC;
-        pre[u] = (c * a.H + r) * a.W + col;
-        prc[u] = (r << 16) | col;
+        prc[u] = ((uint32_t)c << 24) | ((uint32_t)r << 8) | (uint32_t)col;
     }
     const int per_image = a.tiles_x * a.tiles_y, ntiles = per_image * a.B;
     uint32_t stage[8];
@@ -1946,9 +1971,10 @@ conv_stem_kernel(const StemArgs a) {
         const int origin = (b * a.Cin * a.H + y0) * a.W + x0;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int gy = y0 + (prc[u] >> 16), gx = x0 + (prc[u] & 0xffff);
+            const int c = (int)(prc[u] >> 24), r = (int)((prc[u] >> 8) & 0xffu), col = (int)(prc[u] & 0xffu);
+            const int gy = y0 + r, gx = x0 + col;
             const bool ok = (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-            const uint32_t o = ok ? (uint32_t)((origin + pre[u]) * 4) : 0x80000000u;
+            const uint32_t o = ok ? (uint32_t)((origin + (c * a.H + r) * a.W + col) * 4) : 0x80000000u;
             stage[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o, 0, 0);
         }
     };
@@ -1965,6 +1991,9 @@ conv_stem_kernel(const StemArgs a) {
                                    (uint32_t)((((q * STEM_PR + pr) * 2 + (pc & 1)) * STEM_HALF + (pc >> 1)) * 16)};
     }
     const bool last_strip_ok = (w + 4 * (STEM_STRIPS / 4 - 1)) * 16 + n < STEM_NPIX;   // only the last strip runs over
+    char* const w2l = lds + STEM_IN_BYTES + STEM_L0_BYTES + STEM_TAB_BYTES + STEM_FIRST_BYTES;   // TAIL: the 1x1 layer's weights
+    if constexpr (TAIL)
+        *reinterpret_cast<u32x4*>(w2l + threadIdx.x * 16) = *reinterpret_cast<const u32x4*>(a.w2 + threadIdx.x * 8);
     const TileWalk tw = tile_walk(ntiles);
     if (tw.first >= tw.end) return;
     const int step = tw.step, last = tw.end - 1;
@@ -1999,6 +2028,14 @@ conv_stem_kernel(const StemArgs a) {
         // the second layer's zero padding: tiles that reach over the image's edge zero them afterwards (same
         // wave, same LDS addresses, so in order), instead of every strip of every tile selecting per value.
         const int y_first = 2 * oy0 - 1, x_first = 2 * ox0 - 1;
+        bf16x8 wf[2], wl[2];
+        f32x4 bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wf[i] = __builtin_bit_cast(bf16x8, first_tab[(0 + i) * 64]);
+            wl[i] = __builtin_bit_cast(bf16x8, first_tab[(2 + i) * 64]);
+            bv[i] = __builtin_bit_cast(f32x4, first_tab[(4 + i) * 64]);
+        }
 #pragma unroll 1
         for (int i = 0; i < STEM_STRIPS / 4; ++i) {
             const u32x2 st = strip_tab[i * 256];
@@ -2093,7 +2130,41 @@ conv_stem_kernel(const StemArgs a) {
             const int y = oy0 + slot / STEM_TX, x = ox0 + slot % STEM_TX;
             return (y < a.Ho && x < a.Wo) ? ((long long)b * a.Ho + y) * a.Wo + x : -1;
         };
-        tile_store<STEM_TY * STEM_TX, 64, 256>(l0, a.dst, 64, 0, pix);
+        if constexpr (!TAIL) {
+            tile_store<STEM_TY * STEM_TX, 64, 256>(l0, a.dst, 64, 0, pix);
+        } else {
+            // ---- E: 1x1 layer on the parked tile; wave w takes pixel groups 2w and 2w + 1, both channel groups
+#pragma unroll 1
+            for (int g = 0; g < 2; ++g) {
+                const int slot = (2 * w + g) * 16 + n;
+                f32x4 acc2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 yf = *reinterpret_cast<const bf16x8*>(l0 + tile_addr<64>(slot, ks * 32 + q * 8));
+#pragma unroll
+                    for (int cg = 0; cg < 2; ++cg) {
+                        const bf16x8 wq = *reinterpret_cast<const bf16x8*>(w2l + ((ks * 32 + cg * 16 + n) * 32 + q * 8) * 2);
+                        acc2[cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq, yf, acc2[cg], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    const int chl = cg * 16 + cq;
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(a.b2 + chl);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float xx = acc2[cg][r] + bs[r];
+                        if (a.leaky2) xx = xx > 0.f ? xx : 0.1f * xx;
+                        v[r] = xx;
+                    }
+                    tile_put<32>(lds, slot, chl, v, false);
+                }
+            }
+            tile_store<STEM_TY * STEM_TX, 64, 256>(l0, a.dst, 64, 0, pix);
+            __syncthreads();
+            tile_store<STEM_TY * STEM_TX, 32, 256>(lds, a.dst2, 32, 0, pix);
+        }
     }
 }
 
@@ -2984,7 +3055,8 @@ extern "C" int yolo_amd_conv_query(const yolo_amd_conv_desc* d, yolo_amd_conv_ch
 }
 
 // descs[0] (first layer, fuse_next set) and descs[1] as one launch
-static int launch_stem(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc& d1, hipStream_t stream) {
+static int launch_stem(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc& d1, const yolo_amd_conv_desc* d2,
+                       hipStream_t stream) {
     YA_REQUIRE(d0.first_layer && d0.ksize == 3 && d0.stride == 1 && d0.c0 >= 1 && d0.c0 <= 3 && d0.c1 == 0 &&
                    d0.cout == 32 && !d0.residual && !d0.dst_fp32 && d0.up0 == 0,
                "conv: the fused stem needs a 3x3 stride-1 first layer with <= 3 input and 32 output channels");
@@ -3006,7 +3078,19 @@ static int launch_stem(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc& d
     a.tiles_x = (a.Wo + STEM_TX - 1) / STEM_TX; a.tiles_y = (a.Ho + STEM_TY - 1) / STEM_TY;
     const long long ntiles = (long long)a.tiles_x * a.tiles_y * a.B;
     dim3 grid((unsigned)std::min<long long>(ntiles, 256 * 2));
-    hipLaunchKernelGGL(conv_stem_kernel, grid, dim3(256), 0, stream, a);
+    a.w2 = nullptr; a.b2 = nullptr; a.dst2 = nullptr; a.leaky2 = 0;
+    if (d2) {
+        YA_REQUIRE(!d2->first_layer && d2->ksize == 1 && d2->stride == 1 && d2->c0 == 64 && d2->c1 == 0 &&
+                       d2->cout == 32 && d2->cout_pad == 32 && d2->k_pad == 64 && !d2->residual && !d2->dst_fp32 &&
+                       d2->up0 == 0 && !d2->decode && !d2->fuse_next && !d2->bn_train && d2->B == d0.B &&
+                       d2->H == a.Ho && d2->W == a.Wo && d2->src0 == d1.dst,
+                   "conv: the fused stem's third layer must be a 1x1 stride-1 64 -> 32 layer on the second layer's output");
+        YA_REQUIRE(d2->weight && d2->bias && d2->dst, "conv: null pointer");
+        a.w2 = (const __bf16*)d2->weight; a.b2 = d2->bias; a.dst2 = (__bf16*)d2->dst; a.leaky2 = d2->leaky;
+        hipLaunchKernelGGL(conv_stem_kernel<true>, grid, dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(conv_stem_kernel<false>, grid, dim3(256), 0, stream, a);
+    }
     return YA_OK;
 }
 
@@ -3060,9 +3144,10 @@ extern "C" int yolo_amd_conv_forward(const yolo_amd_conv_desc* descs, int n, con
     for (int i = 0; i < n; ++i) {
         int rc;
         if (descs[i].first_layer && descs[i].fuse_next) {
-            YA_REQUIRE(i + 1 < n, "conv_forward: fuse_next on the last descriptor");
-            rc = launch_stem(descs[i], descs[i + 1], stream);
-            ++i;
+            const int more = descs[i].fuse_next == 2 ? 2 : 1;      // 2: the 1x1 layer behind as well
+            YA_REQUIRE(i + more < n, "conv_forward: fuse_next reaches past the last descriptor");
+            rc = launch_stem(descs[i], descs[i + 1], more == 2 ? &descs[i + 2] : nullptr, stream);
+            i += more;
         } else if (descs[i].fuse_next) {
             YA_REQUIRE(i + 1 < n, "conv_forward: fuse_next on the last descriptor");
             rc = launch_block64(descs[i], descs[i + 1], zero_page, stream);

@@ -291,6 +291,18 @@ class Plan:
                     and e1["k"] == 3 and e1["stride"] == 2 and e1["cout"] == 64 and not o1["fp32"]):
                 self.descs[0].fuse_next = 1
                 self.fused_stem = True
+                # ... and the 1x1 layer behind them (64 -> 32, the first residual block's
+                # squeeze) is computed from the second layer's tile while it is in LDS
+                # (fuse_next = 2: this and the next two descriptors); YOLO_AMD_STEM_TAIL=0
+                # leaves it a launch of its own.
+                if (len(ops) >= 3 and os.environ.get("YOLO_AMD_STEM_TAIL", "1") != "0"
+                        and os.environ.get("YOLO_AMD_BLOCK", "0") != "1"):      # (that plan fuses the layer forwards)
+                    o2 = ops[2]
+                    e2 = o2["ent"]
+                    if (e2["k"] == 1 and e2["stride"] == 1 and e2["cout"] == 32 and not o2["res"]
+                            and o2["src"] == [(f"L{o1['index']}", 64, 0)] and not o2["fp32"]
+                            and self.descs[2].cout_pad == 32):
+                        self.descs[0].fuse_next = 2
         # The first residual block (1x1 64 -> 32, 3x3 32 -> 64, shortcut from the block's
         # input) CAN run as one launch when nothing else reads the 1x1 layer's output: its 32
         # channels then never go to memory and the block's input is read once (366 MB of HBM
