@@ -303,7 +303,10 @@ def write_layer_table(path, plan, layers, per_launch, scale, B, H):
         ops = plan.ops[g["first_op"]:g["first_op"] + g["n_ops"]]
         rows = [by_index[o["index"]] for o in ops]
         fl, by = sum(r["flops"] for r in rows), sum(r["bytes"] for r in rows)
-        if g["n_ops"] >= 2:       # a fused group: the first of the layers' output never goes to memory
+        fam_fused = g["family"].startswith(("conv_stem", "conv_block"))
+        if g["n_ops"] == 2 and not fam_fused:   # a 1x1 layer in the epilogue of the layer in front: that
+            by -= B * ops[0]["Ho"] * ops[0]["Wo"] * ops[0]["ent"]["cout"] * 2     # layer's output is written, not re-read
+        elif g["n_ops"] >= 2:     # a fused group: the first of the layers' output never goes to memory
             inter = B * ops[0]["Ho"] * ops[0]["Wo"] * ops[0]["ent"]["cout"] * 2
             by -= 2 * inter
             if g["n_ops"] == 3:   # ... and the third layer takes the second one's output from LDS (it is still written)
@@ -494,8 +497,7 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = world * B * args.steps / elapsed
         achieved = flops_per_batch / (conv_ms * 1e-3) / 1e12
-        n_convs = len(plan.ops) - (1 if getattr(plan, "fused_stem", False) else 0) - \
-            (1 if getattr(plan, "fused_block", False) else 0)
+        n_convs = len(plan.ops) - sum(int(d.fuse_next) for d in plan.descs)      # launches: a fused group is one
         N = plan.N
         stack = {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                  "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK_TFLOPS, 4),

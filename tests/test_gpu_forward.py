@@ -472,6 +472,64 @@ def test_stem_in_one_launch_gives_the_separate_launches_bits(B, H, W):
     assert lib.yolo_amd_conv_forward(d, 2, zero.data_ptr(), stream) < 0      # reaches past the array
 
 
+@pytest.mark.parametrize("B,H,W,stride,res", [(2, 52, 52, 2, False), (1, 37, 21, 2, False), (3, 9, 16, 1, True),
+                                               (2, 104, 104, 2, False), (1, 26, 26, 2, True)])
+def test_a_1x1_layer_in_the_epilogue_of_the_3x3_layer_in_front_gives_the_two_launches_bits(B, H, W, stride, res, monkeypatch):
+    """3x3 64 -> 128 (stride 2, or stride 1 with a shortcut) with fuse_next, then 1x1 128 -> 64
+    on its output: one launch where the 3x3 layer runs the 128-channel-tile im2col kernel
+    (conv_igemm_kernel ... TAIL), two where it does not (the 26 x 26 case is made to take the
+    one-step activation tile); both outputs must be the bits of two separate launches either way."""
+    from yolo_amd import _lib
+    from yolo_amd._lib import ConvDesc, lib, check
+    from yolo_amd.engine import pack_conv_weights
+    set_knob(monkeypatch, "YOLO_AMD_CONV_BN128_MIN", "0")      # small cases keep the 128-channel tile
+    set_knob(monkeypatch, "YOLO_AMD_CONV_BN64_MIN", "0")
+    if H == 26:
+        set_knob(monkeypatch, "YOLO_AMD_CONV_AMUL", "1")
+    r = gi.rs(case_seed(f"tail_{B}_{H}_{W}_{stride}"))
+    dev = torch.device("cuda")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    x = torch.from_numpy(r.standard_normal((B, H, W, 64)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    rs_ = torch.from_numpy(r.standard_normal((B, Ho, Wo, 128)).astype(np.float32)).to(dev).to(torch.bfloat16)
+    w3 = torch.from_numpy((r.standard_normal((128, 64, 3, 3)) * np.sqrt(2.0 / 576)).astype(np.float32))
+    w1 = torch.from_numpy((r.standard_normal((64, 128, 1, 1)) * np.sqrt(2.0 / 128)).astype(np.float32))
+    wk3 = pack_conv_weights(w3.permute(0, 2, 3, 1).reshape(128, 576).to(dev), 128)
+    wk1 = pack_conv_weights(w1.permute(0, 2, 3, 1).reshape(64, 128).to(dev), 64)
+    b3, b1 = (torch.from_numpy(r.normal(0, 0.3, c).astype(np.float32)).to(dev) for c in (128, 64))
+    zero = torch.zeros(1024, dtype=torch.uint8, device=dev)
+    stream = _lib.current_stream_ptr(dev)
+
+    def run(fuse):
+        y = torch.full((B, Ho, Wo, 128), float("nan"), dtype=torch.bfloat16, device=dev)
+        z = torch.full((B, Ho, Wo, 64), float("nan"), dtype=torch.bfloat16, device=dev)
+        d = (ConvDesc * 2)()
+        d[0].src0, d[0].weight, d[0].bias, d[0].dst = x.data_ptr(), wk3.data_ptr(), b3.data_ptr(), y.data_ptr()
+        d[0].residual = rs_.data_ptr() if res else None
+        d[0].c0, d[0].B, d[0].H, d[0].W = 64, B, H, W
+        d[0].cout, d[0].cout_pad, d[0].ksize, d[0].stride, d[0].k_pad, d[0].leaky = 128, 128, 3, stride, 576, 1
+        d[0].fuse_next = fuse
+        d[1].src0, d[1].weight, d[1].bias, d[1].dst = y.data_ptr(), wk1.data_ptr(), b1.data_ptr(), z.data_ptr()
+        d[1].c0, d[1].B, d[1].H, d[1].W = 128, B, Ho, Wo
+        d[1].cout, d[1].cout_pad, d[1].ksize, d[1].stride, d[1].k_pad, d[1].leaky = 64, 64, 1, 1, 128, 1
+        check(lib.yolo_amd_conv_forward(d, 2, zero.data_ptr(), stream), f"3x3 + 1x1, fuse_next {fuse}")
+        torch.cuda.synchronize()
+        return y, z, d
+
+    y0, z0, d = run(0)
+    assert not bool(torch.isnan(y0.float()).any()) and not bool(torch.isnan(z0.float()).any())
+    ch = _lib.conv_choice(d[0])
+    print(f"\n3x3 layer: {ch}")
+    assert ch["kernel"] == "igemm" and ch["bn"] == 128
+    assert ch["act_ksteps"] == (1 if H == 26 else 2), "26 x 26 covers the two-launch form, the others the one-launch form"
+    for _ in range(2):
+        y1, z1, d = run(1)
+        assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)), "3x3 layer's output"
+        assert torch.equal(z1.view(torch.int16), z0.view(torch.int16)), "1x1 layer's output"
+    d[1].stride = 2
+    assert lib.yolo_amd_conv_forward(d, 2, zero.data_ptr(), stream) < 0
+    assert b"fuse_next on a 3x3 layer" in lib.yolo_amd_last_error()
+
+
 # ------------------------------------------------------------------ whole forward
 def _rel_err(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b) / (np.linalg.norm(b) + 1e-30))

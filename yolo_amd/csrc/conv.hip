@@ -63,6 +63,11 @@ struct ConvArgs {
     int ksplit, kslices;
     long long* trace;      // development aid, null unless built with -DYOLO_AMD_DEV_TRACE: per workgroup
                            // eight words as in Conv3Args::trace
+    // TAIL kernels: the 1x1 layer (128 -> 64) that reads this layer's output
+    const __bf16* w2;      // [4][64][32] bf16 (K-tile major)
+    const float* b2;
+    __bf16* dst2;
+    int leaky2;
 };
 
 
@@ -256,7 +261,11 @@ __device__ __forceinline__ void wait_stages(int stages) {
 // 128-byte line per pixel when BK = 32) while the weight tile stays BK deep, so
 // every line the activation gather pulls from L2 is used completely and the
 // ring still fits three workgroups per CU.
-template <int BM, int BN, int BK, int WAVES_M, int NSTAGE, int AMUL = 1>
+// TAIL (BN = 128 = all of the layer's channels): the 1x1 layer behind this one (128 -> 64
+// channels) is computed from the output tile while it sits in LDS -- four K-steps per pixel
+// group in ascending order, as this kernel would run that layer on its own (same bits) --
+// and stored as well: that layer's launch, which read the 128 channels back, is saved.
+template <int BM, int BN, int BK, int WAVES_M, int NSTAGE, int AMUL = 1, bool TAIL = false>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(const ConvArgs a) {
     constexpr int BKA = BK * AMUL;             // depth of the activation tile
@@ -633,6 +642,14 @@ conv_igemm_kernel(const ConvArgs a) {
     if (!a.dst_fp32 && (a.Cout & 7) == 0) {
         auto pix = [&](int slot) -> long long { return m0 + slot < a.M ? (long long)(m0 + slot) : -1; };
         __syncthreads();                       // operand stages are dead from here on
+        constexpr int W2_BYTES = 4 * 64 * 32 * 2;
+        char* const w2l = lds + EPI_BYTES;     // TAIL: the 1x1 layer's weights, later its output tile
+        if constexpr (TAIL) {
+            static_assert(BM == 128 && BN == 128 && EPI_BYTES + W2_BYTES <= LDS_BYTES, "tail: tile and weights share the LDS");
+#pragma unroll
+            for (int i = 0; i < W2_BYTES / 1024 / 4; ++i)
+                lds_dma16(a.w2 + ((w + 4 * i) * 64 + lane) * 8, w2l + (w + 4 * i) * 1024);
+        }
         if (a.res) {
             tile_load_residual<BM, BN, 256>(lds, a.res, a.zero, a.Cout, n0, w, lane, pix);
             __syncthreads();
@@ -655,9 +672,54 @@ conv_igemm_kernel(const ConvArgs a) {
                 tile_put<BN>(lds, slot, chl, v, a.res != nullptr);
             }
         }
+        if constexpr (TAIL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         stamp(6);
-        tile_store<BM, BN, 256>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
+        if constexpr (!TAIL) {
+            tile_store<BM, BN, 256>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
+        } else {
+            // wave w: pixel groups 2w and 2w + 1, all four channel groups of the 1x1 layer
+            const int q = lane >> 4;
+            f32x4 acc2[2][4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) acc2[g][cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 yf[2], wq[4];
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    yf[g] = *reinterpret_cast<const bf16x8*>(lds + tile_addr<BN>((2 * w + g) * 16 + px, ks * 32 + q * 8));
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg)
+                    wq[cg] = *reinterpret_cast<const bf16x8*>(w2l + ((ks * 64 + cg * 16 + px) * 32 + q * 8) * 2);
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int cg = 0; cg < 4; ++cg)
+                        acc2[g][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[cg], yf[g], acc2[g][cg], 0, 0, 0);
+            }
+            tile_store<BM, BN, 256>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
+            __syncthreads();                   // every wave has read the weights: their LDS takes the output tile
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int cg = 0; cg < 4; ++cg) {
+                    const int chl = cg * 16 + cq;
+                    const f32x4 bs = *reinterpret_cast<const f32x4*>(a.b2 + chl);
+                    float v[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = acc2[g][cg][r] + bs[r];
+                        if (a.leaky2) x = x > 0.f ? x : 0.1f * x;
+                        v[r] = x;
+                    }
+                    tile_put<64>(w2l, (2 * w + g) * 16 + px, chl, v, false);
+                }
+            __syncthreads();
+            tile_store<BM, 64, 256>(w2l, a.dst2, 64, 0, pix);
+        }
         stamp(3);
         return;
     }
@@ -2559,11 +2621,11 @@ conv_splitk_finish_kernel(const FinishArgs a) {
     else reinterpret_cast<__bf16*>(a.dst)[e] = (__bf16)x;
 }
 
-template <int BM, int BN, int BK, int WAVES_M, int NSTAGE, int AMUL = 1>
+template <int BM, int BN, int BK, int WAVES_M, int NSTAGE, int AMUL = 1, bool TAIL = false>
 static void launch_igemm(ConvArgs a, hipStream_t stream) {
     a.tiles_m = (a.M + BM - 1) / BM;
     if (a.kslices > 1) a.ksplit = a.ksplit * 32 / BK;          // planned in steps of 32
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, NSTAGE, AMUL>),
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, NSTAGE, AMUL, TAIL>),
                        dim3(a.tiles_m * a.tiles_n, a.kslices), dim3(256), 0, stream, a);
 }
 
@@ -2716,7 +2778,7 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
     if (with_ptrs) YA_REQUIRE(d.c1 == 0 || d.src1, "conv: src1 missing");
     YA_REQUIRE(d.up0 == 0 || (d.up0 == 1 && d.ksize == 1 && d.H % 2 == 0 && d.W % 2 == 0),
                "conv: an upsampled source is supported for 1x1 convolutions only");
-    if (d.fuse_next) {
+    if (d.fuse_next && d.ksize == 1) {
         // the first residual block as one launch: this 1x1 layer in front of the 3x3 layer of the next
         // descriptor (launch_block64 checks the pair)
         YA_REQUIRE(d.ksize == 1 && d.stride == 1 && d.c0 == 64 && d.c1 == 0 && d.up0 == 0 && d.cout == 32 &&
@@ -2847,7 +2909,9 @@ static int choose_conv(const yolo_amd_conv_desc& d, bool with_ptrs, ConvChoice* 
     return YA_OK;
 }
 
-static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream) {
+// tail: a 1x1 layer to run in this layer's epilogue (launch_conv_tail has checked that the kernel can)
+static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream,
+                       const yolo_amd_conv_desc* tail = nullptr) {
     ConvChoice c;
     const int rc = choose_conv(d, true, &c);
     if (rc != YA_OK) return rc;
@@ -2964,6 +3028,14 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
 #ifdef YOLO_AMD_DEV_TRACE
     a.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
 #endif
+    a.w2 = nullptr; a.b2 = nullptr; a.dst2 = nullptr; a.leaky2 = 0;
+    if (tail) {
+        YA_REQUIRE(c.amul == 2 && BN == 128 && c.kslices == 1 && a.tiles_n == 1 && !d.dst_fp32,
+                   "conv: this layer's kernel cannot take a 1x1 layer in its epilogue");
+        a.w2 = (const __bf16*)tail->weight; a.b2 = tail->bias; a.dst2 = (__bf16*)tail->dst; a.leaky2 = tail->leaky;
+        launch_igemm<128, 128, 32, 2, 2, 2, true>(a, stream);
+        return YA_OK;
+    }
     FinishArgs f{};
     if (c.kslices > 1) {
         f.partial = (const float*)d.splitk_ws; f.bias = a.bias; f.res = a.res; f.dst = a.dst;
@@ -3123,6 +3195,31 @@ static int launch_block64(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc
 
 // A layer whose BatchNorm runs on batch statistics: the convolution alone into the fp32
 // scratch, then the statistics and the normalising pass of bn.hip.
+static int launch_conv_bn_train(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream);
+
+// descs[0] (3x3, 128 output channels, fuse_next set) and descs[1] (1x1, 128 -> 64, on descs[0]'s
+// output): one launch where descs[0] runs the kernel that holds all 128 channels of a pixel tile
+// in one workgroup, else two launches -- the results are the same bits either way
+static int launch_conv_tail(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc& d1, const void* zero_page,
+                            hipStream_t stream) {
+    ConvChoice c;
+    const int rc = choose_conv(d0, true, &c);
+    if (rc != YA_OK) return rc;
+    YA_REQUIRE(!d1.first_layer && d1.ksize == 1 && d1.stride == 1 && d1.c0 == d0.cout && d1.c1 == 0 && d1.up0 == 0 &&
+                   !d1.fuse_next && d1.B == d0.B && d1.H == c.Ho && d1.W == c.Wo && d1.src0 == d0.dst,
+               "conv: fuse_next on a 3x3 layer needs a 1x1 stride-1 layer on its output as the next descriptor");
+    const bool can = c.kernel == YOLO_AMD_KERNEL_IGEMM && c.amul == 2 && c.bn == 128 && c.kslices == 1 &&
+                     d0.cout == 128 && d0.cout_pad == 128 && !d0.dst_fp32 && !d0.decode && !d0.bn_train &&
+                     d1.cout == 64 && d1.cout_pad == 64 && d1.k_pad == 128 && !d1.residual && !d1.dst_fp32 &&
+                     !d1.decode && !d1.bn_train && d1.weight && d1.bias && d1.dst;
+    if (can) return launch_conv(d0, zero_page, stream, &d1);
+    yolo_amd_conv_desc plain = d0;
+    plain.fuse_next = 0;
+    const int r0 = d0.bn_train ? launch_conv_bn_train(plain, zero_page, stream) : launch_conv(plain, zero_page, stream);
+    if (r0 != YA_OK) return r0;
+    return d1.bn_train ? launch_conv_bn_train(d1, zero_page, stream) : launch_conv(d1, zero_page, stream);
+}
+
 static int launch_conv_bn_train(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream) {
     YA_REQUIRE(!d.dst_fp32 && !d.decode && !d.fuse_next, "conv: a bn_train layer needs a bf16 dst, no decode, no fuse_next");
     yolo_amd_conv_desc c = d;
@@ -3148,6 +3245,10 @@ extern "C" int yolo_amd_conv_forward(const yolo_amd_conv_desc* descs, int n, con
             YA_REQUIRE(i + more < n, "conv_forward: fuse_next reaches past the last descriptor");
             rc = launch_stem(descs[i], descs[i + 1], more == 2 ? &descs[i + 2] : nullptr, stream);
             i += more;
+        } else if (descs[i].fuse_next && descs[i].ksize == 3) {
+            YA_REQUIRE(i + 1 < n, "conv_forward: fuse_next on the last descriptor");
+            rc = launch_conv_tail(descs[i], descs[i + 1], zero_page, stream);
+            ++i;
         } else if (descs[i].fuse_next) {
             YA_REQUIRE(i + 1 < n, "conv_forward: fuse_next on the last descriptor");
             rc = launch_block64(descs[i], descs[i + 1], zero_page, stream);

@@ -244,29 +244,14 @@ class Plan:
         dev = self.device
         ops, heads, buf_info = build_ops(self.table, B, H, int(self.model.params["channels"]))
         self.ops, self.heads = ops, heads
-        if self.keep_all:
-            for info in buf_info.values():
-                info["last"] = 10 ** 9
-        offsets, peak = place_buffers(buf_info)
-        self.arena = torch.empty(peak + 256, dtype=torch.uint8, device=dev)
-        self.arena_bytes = peak
-        base = (self.arena.data_ptr() + 255) // 256 * 256
-        self.buf_ptr = {bid: base + off for bid, off in offsets.items()}
-        self.zero_page = torch.zeros(1024, dtype=torch.uint8, device=dev)
-
-        # ---- descriptors
+        # ---- descriptors: shapes first (the choice of fused launches below needs them, and
+        # the placement of the buffers needs that choice), pointers once the buffers are placed
         self.descs = (ConvDesc * len(ops))()
         for j, op in enumerate(ops):
             ent, d = op["ent"], self.descs[j]
             (b0, c0, up0) = op["src"][0]
-            d.src0 = 0 if b0 == "input" else self.buf_ptr[b0]
             d.c0, d.up0 = c0, up0
-            if len(op["src"]) == 2:
-                d.src1, d.c1 = self.buf_ptr[op["src"][1][0]], op["src"][1][1]
-            else:
-                d.src1, d.c1 = None, 0
-            d.residual = self.buf_ptr[op["res"]] if op["res"] else None
-            d.dst = self.buf_ptr[f"L{op['index']}"]
+            d.c1 = op["src"][1][1] if len(op["src"]) == 2 else 0
             d.B, d.H, d.W = B, op["H"], op["W"]
             d.cout = ent["cout"]
             d.cout_pad = ent["cout"] if op["first"] else lib.yolo_amd_conv_cout_pad(ent["cout"])
@@ -327,6 +312,54 @@ class Plan:
                     self.descs[j].fuse_next = 1
                     self.fused_block = True
                     break
+        # A 3x3 layer with 128 output channels whose kernel holds all of them for a pixel tile
+        # in one workgroup (the im2col kernel's 128-channel tile with the two-step activation
+        # tile: the stride-2 layer in front of the second group of residual blocks) computes the
+        # 1x1 layer behind it (128 -> 64) from its output tile in LDS: fuse_next on the 3x3 layer,
+        # both outputs written, same bits; the library runs the pair as two launches when the
+        # kernel it picks for the 3x3 layer cannot.  YOLO_AMD_TAIL=0: never (development knob).
+        self.fused_tails = 0
+        if not self.keep_all and not self.train and os.environ.get("YOLO_AMD_TAIL", "1") != "0":
+            for j in range(1, len(ops) - 1):
+                o0, o1 = ops[j], ops[j + 1]
+                e0, e1 = o0["ent"], o1["ent"]
+                if (self.descs[j].fuse_next or self.descs[j - 1].fuse_next or self.descs[j + 1].fuse_next
+                        or (j >= 2 and self.descs[j - 2].fuse_next == 2)):
+                    continue
+                if (e0["k"] == 3 and e0["cout"] == 128 and not o0["first"] and not o0["fp32"]
+                        and e1["k"] == 1 and e1["stride"] == 1 and e1["cout"] == 64 and not o1["res"] and not o1["fp32"]
+                        and o1["src"] == [(f"L{o0['index']}", 128, 0)]
+                        and self.descs[j].cout_pad == 128 and self.descs[j + 1].cout_pad == 64):
+                    ch = _lib.conv_choice(self.descs[j])
+                    if ch["kernel"] == "igemm" and ch["act_ksteps"] == 2 and ch["bn"] == 128 and ch["k_slices"] == 1:
+                        self.descs[j].fuse_next = 1
+                        self.fused_tails += 1
+        # ---- buffers.  A launch that runs several layers writes the later layers' outputs
+        # while the first layer's inputs are still being read: those outputs are alive from
+        # the first layer of the group on, or they could be placed over that input.
+        j = 0
+        while j < len(ops):
+            n = 1 + int(self.descs[j].fuse_next)
+            for o in ops[j + 1:j + n]:
+                info = buf_info[f"L{o['index']}"]
+                info["first"] = min(info["first"], ops[j]["index"])
+            j += n
+        if self.keep_all:
+            for info in buf_info.values():
+                info["last"] = 10 ** 9
+        offsets, peak = place_buffers(buf_info)
+        self.arena = torch.empty(peak + 256, dtype=torch.uint8, device=dev)
+        self.arena_bytes = peak
+        base = (self.arena.data_ptr() + 255) // 256 * 256
+        self.buf_ptr = {bid: base + off for bid, off in offsets.items()}
+        self.zero_page = torch.zeros(1024, dtype=torch.uint8, device=dev)
+        for j, op in enumerate(ops):
+            d = self.descs[j]
+            b0 = op["src"][0][0]
+            d.src0 = 0 if b0 == "input" else self.buf_ptr[b0]
+            d.src1 = self.buf_ptr[op["src"][1][0]] if len(op["src"]) == 2 else None
+            d.residual = self.buf_ptr[op["res"]] if op["res"] else None
+            d.dst = self.buf_ptr[f"L{op['index']}"]
         # Scratch for split reductions: at small batch the deep layers have a few
         # output tiles and K up to 4608; the library cuts such a K into slices when
         # it is lent a buffer (one for all layers: they run in stream order).
