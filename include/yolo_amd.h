@@ -250,7 +250,13 @@ typedef struct {
                           /* layer the value 2 takes the descriptor after the    */
                           /* pair as well, a 1x1 stride-1 64 -> 32 layer on the  */
                           /* second layer's dst: three layers in one launch, the */
-                          /* second and third layers' dst both written.          */
+                          /* second and third layers' dst both written.  On a    */
+                          /* 3x3 layer with 128 output channels, 1 asks for the  */
+                          /* next descriptor (a 1x1 stride-1 128 -> 64 layer on  */
+                          /* this layer's dst) to be computed in this layer's    */
+                          /* epilogue: both dst are written; one launch where    */
+                          /* the kernel picked for the 3x3 layer can do that,    */
+                          /* two otherwise, the same bits either way.            */
     /* Optional device scratch for a split reduction: at small batch a layer
      * with few output tiles and a long K is cut into K slices whose fp32
      * partial sums pass through this buffer (>= yolo_amd_conv_splitk_bytes,

@@ -472,13 +472,18 @@ def test_stem_in_one_launch_gives_the_separate_launches_bits(B, H, W):
     assert lib.yolo_amd_conv_forward(d, 2, zero.data_ptr(), stream) < 0      # reaches past the array
 
 
-@pytest.mark.parametrize("B,H,W,stride,res", [(2, 52, 52, 2, False), (1, 37, 21, 2, False), (3, 9, 16, 1, True),
-                                               (2, 104, 104, 2, False), (1, 26, 26, 2, True)])
-def test_a_1x1_layer_in_the_epilogue_of_the_3x3_layer_in_front_gives_the_two_launches_bits(B, H, W, stride, res, monkeypatch):
+@pytest.mark.parametrize("B,H,W,stride,res,kind", [
+    (2, 52, 52, 2, False, "igemm2"), (1, 37, 21, 2, False, "igemm2"), (3, 9, 16, 1, True, "igemm2"),
+    (2, 104, 104, 2, False, "igemm2"), (1, 26, 26, 2, True, "igemm1"),
+    (4, 104, 104, 1, True, "flat"), (8, 52, 52, 1, False, "flat"), (2, 152, 152, 1, True, "flat"),
+    (3, 104, 91, 1, True, "flat")])
+def test_a_1x1_layer_in_the_epilogue_of_the_3x3_layer_in_front_gives_the_two_launches_bits(B, H, W, stride, res, kind,
+                                                                                           monkeypatch):
     """3x3 64 -> 128 (stride 2, or stride 1 with a shortcut) with fuse_next, then 1x1 128 -> 64
-    on its output: one launch where the 3x3 layer runs the 128-channel-tile im2col kernel
-    (conv_igemm_kernel ... TAIL), two where it does not (the 26 x 26 case is made to take the
-    one-step activation tile); both outputs must be the bits of two separate launches either way."""
+    on its output: one launch where the 3x3 layer runs the 128-channel-tile im2col kernel with the
+    two-step activation tile ("igemm2") or the patch-reuse kernel's flat form ("flat": 13 x 13 and
+    19 x 10 tiles, with and without a shortcut), two where it does not (the 26 x 26 case is made to
+    take the one-step activation tile); both outputs must be the bits of two separate launches."""
     from yolo_amd import _lib
     from yolo_amd._lib import ConvDesc, lib, check
     from yolo_amd.engine import pack_conv_weights
@@ -519,8 +524,11 @@ def test_a_1x1_layer_in_the_epilogue_of_the_3x3_layer_in_front_gives_the_two_lau
     assert not bool(torch.isnan(y0.float()).any()) and not bool(torch.isnan(z0.float()).any())
     ch = _lib.conv_choice(d[0])
     print(f"\n3x3 layer: {ch}")
-    assert ch["kernel"] == "igemm" and ch["bn"] == 128
-    assert ch["act_ksteps"] == (1 if H == 26 else 2), "26 x 26 covers the two-launch form, the others the one-launch form"
+    if kind == "flat":
+        assert ch["kernel"] == "patch" and ch["patch_flat"] == 1 and ch["bn"] == 128, "meant to cover the flat patch-reuse kernel"
+    else:
+        assert ch["kernel"] == "igemm" and ch["bn"] == 128
+        assert ch["act_ksteps"] == (1 if kind == "igemm1" else 2), "igemm1 covers the two-launch form, igemm2 the one-launch form"
     for _ in range(2):
         y1, z1, d = run(1)
         assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)), "3x3 layer's output"

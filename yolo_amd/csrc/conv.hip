@@ -680,6 +680,11 @@ conv_igemm_kernel(const ConvArgs a) {
         } else {
             // wave w: pixel groups 2w and 2w + 1, all four channel groups of the 1x1 layer
             const int q = lane >> 4;
+            // (its bias is asked for ahead of this layer's stores: a load is answered in order with the
+            // stores issued before it and would wait for their acknowledgements)
+            f32x4 b2v[4];
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) b2v[cg] = *reinterpret_cast<const f32x4*>(a.b2 + cg * 16 + cq);
             f32x4 acc2[2][4];
 #pragma unroll
             for (int g = 0; g < 2; ++g)
@@ -700,6 +705,8 @@ conv_igemm_kernel(const ConvArgs a) {
                     for (int cg = 0; cg < 4; ++cg)
                         acc2[g][cg] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[cg], yf[g], acc2[g][cg], 0, 0, 0);
             }
+#pragma unroll
+            for (int cg = 0; cg < 4; ++cg) asm volatile("" : "+v"(b2v[cg]));
             tile_store<BM, BN, 256>(lds, (__bf16*)a.dst, a.Cout, n0, pix);
             __syncthreads();                   // every wave has read the weights: their LDS takes the output tile
 #pragma unroll
@@ -707,7 +714,7 @@ conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int cg = 0; cg < 4; ++cg) {
                     const int chl = cg * 16 + cq;
-                    const f32x4 bs = *reinterpret_cast<const f32x4*>(a.b2 + chl);
+                    const f32x4 bs = b2v[cg];
                     float v[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -817,6 +824,11 @@ struct Conv3Args {
                                        // 100 MHz timestamps (start, K loop entered, K loop done, stores issued), XCC_ID << 32 | HW_ID,
                                        // then two more timestamps (residual tile landed, output tile complete in LDS)
     int prio;                          // raise the wave priority over the MFMA groups (about 1 %; YOLO_AMD_CONV3_PRIO=0 turns it off)
+    // TAIL kernels: the 1x1 layer (128 -> 64) that reads this layer's output (tiles_n = 1)
+    const __bf16* w2;      // [4][64][32] bf16 (K-tile major)
+    const float* b2;
+    __bf16* dst2;
+    int leaky2;
 };
 
 // WAVES = 4: wave cg owns all 11 pixel groups (three workgroups per CU).
@@ -1380,7 +1392,14 @@ conv3x3_patch_kernel(const Conv3Args a) {
 // into a second register set before the MFMAs of tap t, the weights running three taps ahead -- the schedule
 // came out as written, no spill in the loop, and every layer was 3-6 % slower (52.1 against 50.5 us on
 // 256 -> 512 @ 26x26): with four waves per SIMD the wave's own LDS latency is already hidden by the others.
-template <int TH, int TW, int PW, int RSTEP, int NT0>
+// TAIL (one channel tile: all 128 output channels of the layer in this workgroup): the 1x1 layer
+// behind this one (128 -> 64) is computed in the epilogue.  The staged 1 KiB piece of wave (channel
+// group c, half h) for pixel group g IS the MFMA B operand of that layer's K-step c for those 16
+// pixels, so after one workgroup barrier wave (c, h) reads the four pieces of each of its pixel
+// groups -- its own and its three neighbours' -- against the weight fragments of output channels
+// 16 c .. 16 c + 15 (loaded from memory into registers after the K loop), K-steps in ascending order
+// as the im2col kernel runs that layer (same bits), and stores its 32 bytes per pixel.
+template <int TH, int TW, int PW, int RSTEP, int NT0, bool TAIL = false>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 conv3x3_flat_kernel(const Conv3Args a) {
     constexpr int NPIX = TH * TW;                  // output pixels per tile
@@ -1516,10 +1535,11 @@ conv3x3_flat_kernel(const Conv3Args a) {
         // into memory nobody else reads: the first NI at tap 0 into this wave's share of the patch buffer the
         // last chunk does not read (IDLE0 KiB for each of waves 0-3, IDLE1 KiB for each of waves 4-7), two at
         // tap 7 and two at tap 8 into the ring slots those taps no longer fetch weights for.
-        char* const idle = lds + (NCH & 1) * PATCH + (half == 0 ? w * (IDLE0 * 1024) : 4 * IDLE0 * 1024 + (w - 4) * (IDLE1 * 1024));
-        auto res_at = [&](int tp) -> char* {
-            return tp < NI ? idle + tp * 1024 : myring + ((tp - NI) >> 1) * 2048 + ((tp - NI) & 1) * 1024;
+        auto piece_of = [&](int wv, int tp) -> char* {    // wave wv's piece tp (wv in this wave's half)
+            char* const idle_w = lds + (NCH & 1) * PATCH + (half == 0 ? wv * (IDLE0 * 1024) : 4 * IDLE0 * 1024 + (wv - 4) * (IDLE1 * 1024));
+            return tp < NI ? idle_w + tp * 1024 : wring + wv * (RING * PSLOT) + ((tp - NI) >> 1) * 2048 + ((tp - NI) & 1) * 1024;
         };
+        auto res_at = [&](int tp) -> char* { return piece_of(w, tp); };
         auto res_piece = [&](int tp) {
             int ln = lane;
             asm volatile("" : "+v"(ln));
@@ -1612,6 +1632,17 @@ conv3x3_flat_kernel(const Conv3Args a) {
         // ---- epilogue (no workgroup barrier: see the kernel above)
         stamp(2);
         if (!a.dst_fp32 && (a.Cout & 7) == 0) {
+            // TAIL: the 1x1 layer's weight fragments and bias, asked for before this layer's stores go out
+            // (loads and stores are answered in one order: behind the stores they would wait for every store's
+            // acknowledgement)
+            bf16x8 w2f[TAIL ? 4 : 1];
+            f32x4 b2v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (TAIL) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    w2f[ks] = *reinterpret_cast<const bf16x8*>(a.w2 + ((ks * 64 + cg * 16 + r) * 32 + q * 8));
+                b2v = *reinterpret_cast<const f32x4*>(a.b2 + cg * 16 + q * 4);
+            }
             const float slope = a.leaky ? 0.1f : 1.0f;
 #pragma unroll
             for (int tc = 0; tc < 2; ++tc) {
@@ -1625,10 +1656,11 @@ conv3x3_flat_kernel(const Conv3Args a) {
             // is past its last read of the patch buffer the last chunk does not use)
 #pragma unroll
             for (int tp = 0; tp < NTW; ++tp) {
-                if (own_res) {                   // NI pieces went out first, then two pairs
-                    if (tp == 0) wait_vmcnt<4>();
-                    if (tp == NI) wait_vmcnt<2>();
-                    if (tp == NI + 2) wait_vmcnt<0>();
+                if (own_res) {                   // NI pieces went out first, then two pairs (then TAIL's five loads)
+                    constexpr int TL = TAIL ? 5 : 0;
+                    if (tp == 0) wait_vmcnt<4 + TL>();
+                    if (tp == NI) wait_vmcnt<2 + TL>();
+                    if (tp == NI + 2) wait_vmcnt<0 + TL>();
                 }
 #pragma unroll
                 for (int tc = 0; tc < 2; ++tc) {
@@ -1649,15 +1681,73 @@ conv3x3_flat_kernel(const Conv3Args a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             stamp(6);
+            auto store_pieces = [&]() {
 #pragma unroll
-            for (int tp = 0; tp < NTW; ++tp) {
-                const int slot = (tp0 + tp) * 16 + (lane >> 2);
-                int tx;
-                const int ty = row_of(slot, tx);
-                const int ch = n0 + cg * 32 + (((lane & 3) ^ ((lane >> 4) & 3)) * 8);
-                const bf16x8 val = *reinterpret_cast<const bf16x8*>(res_at(tp) + lane * 16);
-                if (slot < NPIX && oy0 + ty < a.H && ox0 + tx < a.W && ch + 8 <= a.Cout)
-                    store_out16((__bf16*)a.dst + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + ch), val);
+                for (int tp = 0; tp < NTW; ++tp) {
+                    const int slot = (tp0 + tp) * 16 + (lane >> 2);
+                    int tx;
+                    const int ty = row_of(slot, tx);
+                    const int ch = n0 + cg * 32 + (((lane & 3) ^ ((lane >> 4) & 3)) * 8);
+                    const bf16x8 val = *reinterpret_cast<const bf16x8*>(res_at(tp) + lane * 16);
+                    if (slot < NPIX && oy0 + ty < a.H && ox0 + tx < a.W && ch + 8 <= a.Cout)
+                        store_out16((__bf16*)a.dst + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * a.Cout + ch), val);
+                }
+            };
+            if constexpr (!TAIL) store_pieces();
+            if constexpr (TAIL) {
+                // (this layer's own stores go out behind the 1x1 layer: a load is answered in order with the
+                // stores issued before it, so the weight fragments would wait for their acknowledgements)
+                __builtin_amdgcn_s_barrier();          // every wave's pieces are written (its LDS writes were waited for above)
+                asm volatile("" ::: "memory");
+                // (the bias is first used under the store's condition: waited for there, the wait would be
+                // repeated in every pixel group's branch, behind the stores of the groups before)
+                asm volatile("" : "+v"(b2v));
+                const float slope2 = a.leaky2 ? 0.1f : 1.0f;
+                // The 16 x 16-channel results go through LDS once more so that whole 128-byte pixels leave in
+                // 16-byte stores (as 8 bytes per lane straight from the accumulators the 44 MB of this output
+                // cost 15 us): 2 KiB per pixel group, in the patch buffer the last chunk read (seven groups)
+                // and, for waves 4-7, the third ring slot of the wave with the group's number -- everybody is
+                // past the K loop behind the barrier above.
+                static_assert(NT0 <= 7 && NG - NT0 <= 5, "places for the 1x1 layer's output groups");
+                char* const dead = lds + ((NCH - 1) & 1) * PATCH;
+                auto out2_at = [&](int tp) -> char* {
+                    return half == 0 ? dead + tp * 2048
+                                     : (tp < 4 ? wring + (4 + tp) * (RING * PSLOT) + 2 * PSLOT : dead + 7 * 2048);
+                };
+#pragma unroll
+                for (int tp = 0; tp < NTW; ++tp) {
+                    f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const bf16x8 yf = *reinterpret_cast<const bf16x8*>(piece_of(half * 4 + ks, tp) + r * 64 + ((q ^ ((r >> 2) & 3)) * 16));
+                        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], yf, acc2, 0, 0, 0);
+                    }
+                    bf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc2[e] + b2v[e];
+                        x = x > 0.f ? x : slope2 * x;
+                        pk[e] = (__bf16)x;
+                    }
+                    *reinterpret_cast<bf16x4*>(out2_at(tp) + r * 128 + (((cg * 2 + (q >> 1)) ^ (r & 7)) * 16) + (q & 1) * 8) = pk;
+                }
+                store_pieces();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int k = 0; k < (2 * NTW + 3) / 4; ++k) {
+                    const int it = cg + 4 * k;               // eight pixels of group it / 2, wave-uniform
+                    if (it < 2 * NTW) {
+                        const int tp = it >> 1, rr = (it & 1) * 8 + (lane >> 3), c8 = lane & 7;
+                        const int slot = (tp0 + tp) * 16 + rr;
+                        int tx;
+                        const int ty = row_of(slot, tx);
+                        const bf16x8 val = *reinterpret_cast<const bf16x8*>(out2_at(tp) + rr * 128 + ((c8 ^ (rr & 7)) * 16));
+                        if (slot < NPIX && oy0 + ty < a.H && ox0 + tx < a.W)
+                            store_out16(a.dst2 + ((((size_t)cb * a.H + oy0 + ty) * a.W + ox0 + tx) * 64 + c8 * 8), val);
+                    }
+                }
             }
             stamp(3);
             return;
@@ -2964,6 +3054,17 @@ static int launch_conv(const yolo_amd_conv_desc& d, const void* zero_page, hipSt
 #ifdef YOLO_AMD_DEV_TRACE
         p.trace = (long long*)env_ptr("YOLO_AMD_CONV3_TRACE");
 #endif
+        p.w2 = nullptr; p.b2 = nullptr; p.dst2 = nullptr; p.leaky2 = 0;
+        if (tail) {
+            YA_REQUIRE(c.flat && p.tiles_n == 1 && d.cout == 128 && !d.dst_fp32,
+                       "conv: this layer's kernel cannot take a 1x1 layer in its epilogue");
+            p.w2 = (const __bf16*)tail->weight; p.b2 = tail->bias; p.dst2 = (__bf16*)tail->dst; p.leaky2 = tail->leaky;
+            if (c.th == 19)
+                hipLaunchKernelGGL((conv3x3_flat_kernel<19, 10, 12, 1, 7, true>), dim3(p.ntiles), dim3(512), 0, stream, p);
+            else
+                hipLaunchKernelGGL((conv3x3_flat_kernel<13, 13, 15, 3, 7, true>), dim3(p.ntiles), dim3(512), 0, stream, p);
+            return YA_OK;
+        }
         if (c.flat && c.th == 19)
             hipLaunchKernelGGL((conv3x3_flat_kernel<19, 10, 12, 1, 7>), dim3(p.ntiles * p.tiles_n), dim3(512), 0, stream, p);
         else if (c.flat && env_int("YOLO_AMD_CONV3_SPLIT", 7) == 6)
@@ -3198,8 +3299,10 @@ static int launch_block64(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc
 static int launch_conv_bn_train(const yolo_amd_conv_desc& d, const void* zero_page, hipStream_t stream);
 
 // descs[0] (3x3, 128 output channels, fuse_next set) and descs[1] (1x1, 128 -> 64, on descs[0]'s
-// output): one launch where descs[0] runs the kernel that holds all 128 channels of a pixel tile
-// in one workgroup, else two launches -- the results are the same bits either way
+// output): one launch where descs[0] runs a kernel that holds all 128 channels of a pixel tile
+// in one workgroup (the im2col kernel's 128-channel tile with the two-step activation tile, the
+// patch-reuse kernel's flat form), else two launches -- the results are the same bits either way.
+// YOLO_AMD_TAIL (development knob): bit 0 allows the im2col form, bit 1 the patch-reuse form.
 static int launch_conv_tail(const yolo_amd_conv_desc& d0, const yolo_amd_conv_desc& d1, const void* zero_page,
                             hipStream_t stream) {
     ConvChoice c;
@@ -3208,7 +3311,9 @@ static int launch_conv_tail(const yolo_amd_conv_desc& d0, const yolo_amd_conv_de
     YA_REQUIRE(!d1.first_layer && d1.ksize == 1 && d1.stride == 1 && d1.c0 == d0.cout && d1.c1 == 0 && d1.up0 == 0 &&
                    !d1.fuse_next && d1.B == d0.B && d1.H == c.Ho && d1.W == c.Wo && d1.src0 == d0.dst,
                "conv: fuse_next on a 3x3 layer needs a 1x1 stride-1 layer on its output as the next descriptor");
-    const bool can = c.kernel == YOLO_AMD_KERNEL_IGEMM && c.amul == 2 && c.bn == 128 && c.kslices == 1 &&
+    const bool holds_all = (c.kernel == YOLO_AMD_KERNEL_IGEMM && c.amul == 2 && c.bn == 128 && c.kslices == 1) ||
+                           (c.kernel == YOLO_AMD_KERNEL_PATCH && c.flat && c.bn == 128);
+    const bool can = holds_all && env_int("YOLO_AMD_TAIL", 3) & (c.kernel == YOLO_AMD_KERNEL_PATCH ? 2 : 1) &&
                      d0.cout == 128 && d0.cout_pad == 128 && !d0.dst_fp32 && !d0.decode && !d0.bn_train &&
                      d1.cout == 64 && d1.cout_pad == 64 && d1.k_pad == 128 && !d1.residual && !d1.dst_fp32 &&
                      !d1.decode && !d1.bn_train && d1.weight && d1.bias && d1.dst;

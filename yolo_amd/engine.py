@@ -314,7 +314,8 @@ class Plan:
                     break
         # A 3x3 layer with 128 output channels whose kernel holds all of them for a pixel tile
         # in one workgroup (the im2col kernel's 128-channel tile with the two-step activation
-        # tile: the stride-2 layer in front of the second group of residual blocks) computes the
+        # tile: the stride-2 layer in front of the second group of residual blocks; the flat
+        # patch-reuse kernel: the 3x3 layer of the first block of that group) computes the
         # 1x1 layer behind it (128 -> 64) from its output tile in LDS: fuse_next on the 3x3 layer,
         # both outputs written, same bits; the library runs the pair as two launches when the
         # kernel it picks for the 3x3 layer cannot.  YOLO_AMD_TAIL=0: never (development knob).
@@ -331,7 +332,8 @@ class Plan:
                         and o1["src"] == [(f"L{o0['index']}", 128, 0)]
                         and self.descs[j].cout_pad == 128 and self.descs[j + 1].cout_pad == 64):
                     ch = _lib.conv_choice(self.descs[j])
-                    if ch["kernel"] == "igemm" and ch["act_ksteps"] == 2 and ch["bn"] == 128 and ch["k_slices"] == 1:
+                    if ((ch["kernel"] == "igemm" and ch["act_ksteps"] == 2 and ch["bn"] == 128 and ch["k_slices"] == 1)
+                            or (ch["kernel"] == "patch" and ch["patch_flat"] and ch["bn"] == 128)):
                         self.descs[j].fuse_next = 1
                         self.fused_tails += 1
         # ---- buffers.  A launch that runs several layers writes the later layers' outputs
