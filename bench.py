@@ -527,9 +527,11 @@ def main():
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             tr = None
             if traffic and "<" not in dom:         # (the im2col instantiations share one name stem)
-                tkey = next((k for k in traffic if k.startswith(dom)), None)
-                if tkey:
-                    tr = round(traffic[tkey]["read_bytes_per_launch"] + traffic[tkey]["write_bytes_per_launch"])
+                tkeys = [k for k in traffic if k.startswith(dom)]      # every instantiation of the family
+                if tkeys:
+                    n_fam = sum(traffic[k]["launches_profiled"] for k in tkeys)
+                    tr = round(sum((traffic[k]["read_bytes_per_launch"] + traffic[k]["write_bytes_per_launch"]) *
+                                   traffic[k]["launches_profiled"] for k in tkeys) / max(1, n_fam))
             roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_DENSE_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_DENSE_PEAK_TFLOPS, 4), "traffic": tr,
                         "kernel": f"{dom} ({a['launches']} launches per step, "

@@ -127,6 +127,42 @@ def test_fused_plan_structure_and_buffer_placement(B, H):
             assert d1 <= offsets[r] or offsets[r] + info[r]["bytes"] <= d0
 
 
+def test_outputs_of_a_fused_group_never_land_on_the_groups_inputs():
+    """Launches that run several layers (the stem with the 1x1 layer behind it, a 3x3 layer with
+    the 1x1 layer behind it) write the later layers' outputs while the first layer's inputs are
+    still read by other workgroups.  Without the lifetime extension the placement puts block 6's
+    output exactly there: on block 4's output, which dies with block 5."""
+    blocks = orc.parse_cfg_text(yolov3_cfg_text())
+    table = engine.graph_from_blocks(blocks, 3, 80, 3)
+
+    def group_hazards(extend):
+        ops, _, info = engine.build_ops(table, 32, 416, 3)
+        fuse = [0] * len(ops)
+        fuse[0] = 2                                    # blocks 0, 1, 2
+        for j, o in enumerate(ops):
+            if o["index"] in (5, 7):                   # 3x3 64 -> 128 with the 1x1 128 -> 64 behind it
+                fuse[j] = 1
+        if extend:
+            engine.extend_fused_lifetimes(ops, info, fuse)
+        offsets, _ = engine.place_buffers(info)
+        bad = []
+        j = 0
+        while j < len(ops):
+            n = 1 + fuse[j]
+            group = ops[j:j + n]
+            outs = {f"L{o['index']}" for o in group}
+            reads = {s[0] for o in group for s in o["src"] if s[0] != "input"} | {o["res"] for o in group if o["res"]}
+            for r in reads - outs:
+                for w in outs:
+                    if not (offsets[w] + info[w]["bytes"] <= offsets[r] or offsets[r] + info[r]["bytes"] <= offsets[w]):
+                        bad.append((w, r))
+            j += n
+        return bad
+
+    assert group_hazards(True) == []
+    assert ("L6", "L3") in group_hazards(False), "the case this guards against no longer arises: pick another"
+
+
 def test_unsupported_graphs_are_rejected_not_mis_executed():
     blocks = orc.parse_cfg_text(yolov3_cfg_text())
     blocks[85]["stride"] = "4"

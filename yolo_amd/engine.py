@@ -207,6 +207,20 @@ def place_buffers(buf_info):
     return offsets, peak
 
 
+def extend_fused_lifetimes(ops, buf_info, fuse_next):
+    """fuse_next[j] > 0: ops j .. j + fuse_next[j] run as one launch.  Every output of
+    the group is written while the group's first layer is still reading its inputs, so
+    each is made alive from that layer on (place_buffers could otherwise put a later
+    layer's output over the first layer's input, which dies with that layer)."""
+    j = 0
+    while j < len(ops):
+        n = 1 + int(fuse_next[j])
+        for o in ops[j + 1:j + n]:
+            info = buf_info[f"L{o['index']}"]
+            info["first"] = min(info["first"], ops[j]["index"])
+        j += n
+
+
 class Plan:
     """Descriptors and buffers for one (batch, height) shape on one device."""
 
@@ -339,13 +353,7 @@ class Plan:
         # ---- buffers.  A launch that runs several layers writes the later layers' outputs
         # while the first layer's inputs are still being read: those outputs are alive from
         # the first layer of the group on, or they could be placed over that input.
-        j = 0
-        while j < len(ops):
-            n = 1 + int(self.descs[j].fuse_next)
-            for o in ops[j + 1:j + n]:
-                info = buf_info[f"L{o['index']}"]
-                info["first"] = min(info["first"], ops[j]["index"])
-            j += n
+        extend_fused_lifetimes(ops, buf_info, [int(d.fuse_next) for d in self.descs])
         if self.keep_all:
             for info in buf_info.values():
                 info["last"] = 10 ** 9
