@@ -237,6 +237,26 @@ def measure_traffic(argv_tail, steps=3, warmup=1, timeout_s=240):
     return out, None
 
 
+def gemm_calibration(dev, n=8192, reps=10):
+    """What the vendor GEMM library (torch.matmul: hipBLASLt / rocBLAS) sustains on THIS GPU for a large square
+    bf16 product of random data, after the timed region: a yardstick for the MFMA fractions above -- the nominal
+    peak they are priced against is not reached by any bf16 kernel at the board's power limit.  Not part of the path."""
+    a = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+    b = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
+    for _ in range(3):
+        torch.matmul(a, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        torch.matmul(a, b)
+    e1.record()
+    torch.cuda.synchronize()
+    tf = 2.0 * n ** 3 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return {"what": f"torch.matmul {n}^3 bf16, random data, vendor GEMM library", "tflops": round(tf, 1),
+            "frac_of_nominal_peak": round(tf / MFMA_BF16_DENSE_PEAK_TFLOPS, 4)}
+
+
 KERNEL_FAMILY = {"patch": "conv3x3_patch_kernel", "stem": "conv_stem_kernel", "thin": "conv3x3_thin_kernel",
                  "first": "conv_first_kernel", "block": "conv_block64_kernel"}
 
@@ -340,6 +360,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the extra pipelined measurement")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the vendor-GEMM yardstick")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the per-launch event passes")
     ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight per GPU, each on a HIP stream of its own (1: one batch after the other)")
@@ -595,6 +616,8 @@ def main():
             result["hbm_traffic_per_launch"] = {k: {kk: round(vv) for kk, vv in v.items()} for k, v in traffic.items()}
         if pipelined:
             result["pipelined"] = pipelined
+        if world == 1 and not args.no_calibration:
+            result["calibration"] = gemm_calibration(device)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(sd, H, C, A, args.conf, args.nms)
         print(json.dumps(result), flush=True)

@@ -53,6 +53,15 @@ def main():
     print(f"{a.layer}, batch {a.batch}: {nwg} workgroups, {e0.elapsed_time(e1) * 1e3:.1f} us with the stamps in; "
           f"K loop {kloop_us.mean():.1f} us = {taps} taps of {kloop_us.mean() / taps * 1e3:.0f} ns; "
           f"{tot.mean():.0f} s_memtime ticks per tap and wave ({tot.mean() / (kloop_us.mean() / taps * 1e3):.2f} per ns)")
+    # workgroup phases (wave 0's stamps, 10 ns ticks): start, first loads issued, K loop done, pieces staged, end
+    ph = wg[:nwg].astype(np.float64)
+    t_first, t_last = ph[:, 0].min(), ph[:, 3].max()
+    print(f"  workgroup phases, us (mean): set-up {(ph[:, 1] - ph[:, 0]).mean() / 100:.2f}; K loop {(ph[:, 2] - ph[:, 1]).mean() / 100:.2f}; "
+          f"epilogue to pieces staged {(ph[:, 6] - ph[:, 2]).mean() / 100:.2f}; stores issued {(ph[:, 3] - ph[:, 6]).mean() / 100:.2f}; "
+          f"alive {(ph[:, 3] - ph[:, 0]).mean() / 100:.2f}; first start to last end {(t_last - t_first) / 100:.1f}; "
+          f"starts within the first us {int(((ph[:, 0] - t_first) < 100).sum())}")
+    order = np.sort(ph[:, 0] - t_first) / 100
+    print("  start times, us, deciles: " + " ".join(f"{order[int(k * (nwg - 1) / 10)]:.1f}" for k in range(11)))
     for half, nm in ((slice(0, 4), "waves 0-3 (the larger share of the pixel groups)"), (slice(4, 8), "waves 4-7 (the smaller share)")):
         m = per_tap[:, half, :].mean(axis=(0, 1))
         print(f"  {nm}: " + "; ".join(f"{NAMES[i]} {m[i]:.0f}" for i in range(6)) + f"; sum {m.sum():.0f}")
