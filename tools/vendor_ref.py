@@ -49,6 +49,21 @@ def main():
         mm = timed(lambda: torch.matmul(a, bm))
         tf = lambda us: flops / (us * 1e-6) / 1e12
         print(f"{name:22s} {ours:7.1f} {tf(ours):6.0f} {mi:8.1f} {tf(mi):6.0f} {mm:8.1f} {tf(mm):6.0f}")
+    # the 1x1 layers are plain products already: the GEMM library on their shapes (no bias, no activation)
+    print(f"{'layer':22s} {'this library':>14s} {'GEMM (matmul)':>15s}")
+    for name in ("1x1  64->32  @208", "1x1 128->64  @104", "1x1 256->128 @52", "1x1 512->256 @26", "1x1 1024->512 @13"):
+        spec = [s for s in cb.LAYERS if s[0] == name]
+        if not spec:
+            continue
+        spec = spec[0]
+        d, keep, flops, byts = cb.make_desc(B, *spec[1:], dev)
+        ours = timed(lambda: check(lib.yolo_amd_conv_forward(d, 1, zero.data_ptr(), stream), "conv"))
+        H, cin, cout = spec[1], spec[2], spec[3]
+        a = torch.randn(B * H * H, cin, device=dev, dtype=torch.bfloat16)
+        bm = torch.randn(cin, cout, device=dev, dtype=torch.bfloat16) * 0.05
+        mm = timed(lambda: torch.matmul(a, bm))
+        tf = lambda us: flops / (us * 1e-6) / 1e12
+        print(f"{name:22s} {ours:7.1f} {tf(ours):6.0f} {mm:8.1f} {tf(mm):6.0f}")
     # what the GEMM library sustains on this GPU when the shape is large and square
     for n in (4096, 8192):
         a = torch.randn(n, n, device=dev, dtype=torch.bfloat16)
