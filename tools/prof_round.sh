@@ -6,8 +6,8 @@
 TAG=${1:-round3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG; rm -rf $OUT; mkdir -p $OUT
-ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-pipelined --no-traffic --no-kernel-pass --in-flight 1"
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pipelined --no-traffic --no-kernel-pass --in-flight 1 > $OUT/trace.json 2> $OUT/trace.err || { echo "trace pass failed"; tail -5 $OUT/trace.err; exit 1; }
+ARGS="--steps 10 --warmup 3 --no-cpu-baseline --no-calibration --no-pipelined --no-traffic --no-kernel-pass --in-flight 1"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-calibration --no-pipelined --no-traffic --no-kernel-pass --in-flight 1 > $OUT/trace.json 2> $OUT/trace.err || { echo "trace pass failed"; tail -5 $OUT/trace.err; exit 1; }
 run() {
   name=$1; shift
   timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python bench.py $ARGS > $OUT/$name.log 2>&1 || { echo "pass $name failed"; tail -5 $OUT/$name.log; exit 1; }
@@ -28,7 +28,7 @@ for f in glob.glob(f"{out}/trace/**/*kernel_trace.csv", recursive=True):
         rows[fam(r["Kernel_Name"])][1] += d
 tot = sum(v[1] for v in rows.values())
 with open(f"gpurun_out/{tag}_kernel_stats.txt", "w") as fh:
-    fh.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pipelined --no-traffic --no-kernel-pass --in-flight 1\n")
+    fh.write("rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-calibration --no-pipelined --no-traffic --no-kernel-pass --in-flight 1\n")
     fh.write(f"{'kernel':70s} {'calls':>7s} {'avg us':>9s} {'total ms':>9s} {'%':>6s}\n")
     for k, (n, t) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
         fh.write(f"{k[:70]:70s} {n:7d} {t / n:9.1f} {t / 1e3:9.2f} {100 * t / tot:6.2f}\n")
