@@ -20,7 +20,7 @@ __device__ __forceinline__ void dma16(const char* sbase, uint32_t lane_bytes, ui
 
 template <int NREAD, int NDMA, int NMFMA, bool ACC_A>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
-mix_kernel(const char* src, float* sink, int iters, long long* clocks) {
+mix_kernel(const char* src, float* sink, int iters, long long* clocks, uint32_t seed) {
     __shared__ __attribute__((aligned(1024))) char lds[8 * 8192];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -28,9 +28,19 @@ mix_kernel(const char* src, float* sink, int iters, long long* clocks) {
     const uint32_t mybase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)mine;
     const uint32_t lane_bytes = lane * 16;
     // something that is not zero, so that the clock is the clock of real data
-    for (int i = 0; i < 8; ++i)
-        *reinterpret_cast<u32x4*>(mine + i * 1024 + lane * 16) =
-            u32x4{0x3f803f80u ^ (uint32_t)(lane * 0x01010101u), 0x3fa0bf90u + (uint32_t)i, 0xbf853f33u ^ (uint32_t)(lane << 3), 0x3f4cbf19u};
+    for (int i = 0; i < 8; ++i) {
+        u32x4 v = u32x4{0x3f803f80u ^ (uint32_t)(lane * 0x01010101u), 0x3fa0bf90u + (uint32_t)i, 0xbf853f33u ^ (uint32_t)(lane << 3), 0x3f4cbf19u};
+        if (seed) {
+            // random signs and mantissas, magnitudes in [0.5, 2): what activations and weights look like to the multipliers
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint32_t h = seed ^ (blockIdx.x * 0x9E3779B1u) ^ ((uint32_t)(threadIdx.x * 8 + i) * 0x85EBCA77u) ^ ((uint32_t)e * 0xC2B2AE3Du);
+                h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+                v[e] = (h & 0x80ff80ffu) | 0x3f003f00u;
+            }
+        }
+        *reinterpret_cast<u32x4*>(mine + i * 1024 + lane * 16) = v;
+    }
     __syncthreads();
     f32x4 acc[NMFMA];
 #pragma unroll
@@ -79,12 +89,14 @@ mix_kernel(const char* src, float* sink, int iters, long long* clocks) {
 
 static char* src; static float* sink; static long long* clocks; static hipEvent_t e0, e1;
 
+static uint32_t g_seed = 0;
+
 template <int NREAD, int NDMA, int NMFMA, bool ACC_A>
 int run(int grid) {
     const int iters = 20000;
     for (int rep = 0; rep < 2; ++rep) {
         if (rep) CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((mix_kernel<NREAD, NDMA, NMFMA, ACC_A>), dim3(grid), dim3(512), 0, 0, src, sink, rep ? iters : 200, clocks);
+        hipLaunchKernelGGL((mix_kernel<NREAD, NDMA, NMFMA, ACC_A>), dim3(grid), dim3(512), 0, 0, src, sink, rep ? iters : 200, clocks, g_seed);
         if (rep) CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
     }
@@ -98,9 +110,9 @@ int run(int grid) {
     // (s_memtime ticks are not shader cycles under this load -- twelve MFMAs of four waves cannot issue in fewer
     // than 768 cycles and take 615 ticks -- so the rate comes from the HIP events alone)
     const double tf = (double)grid * 8 * iters * NMFMA * 16384.0 / (ms * 1e-3) / 1e12;
-    printf("%2d reads %d DMA %2d MFMA per step and wave, accumulators in %s, %d waves/SIMD: %5.0f TFLOP/s = %.2f us per step "
+    printf("%s data: %2d reads %d DMA %2d MFMA per step and wave, accumulators in %s, %d waves/SIMD: %5.0f TFLOP/s = %.2f us per step "
            "(%.0f s_memtime ticks per step and wave)\n",
-           NREAD, NDMA, NMFMA, ACC_A ? "AGPRs" : "VGPRs", per_simd, tf, ms * 1e3 / iters, cyc);
+           g_seed ? "random" : "patterned", NREAD, NDMA, NMFMA, ACC_A ? "AGPRs" : "VGPRs", per_simd, tf, ms * 1e3 / iters, cyc);
     return 0;
 }
 
@@ -110,6 +122,13 @@ int main() {
     CK(hipMalloc(&sink, (size_t)512 * 512 * sizeof(float)));
     CK(hipMalloc(&clocks, 512 * sizeof(long long)));
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // the same loops on random operands first (the board's power limit sets the clock, and the multipliers'
+    // power follows the bits that toggle): the MFMA stream alone, and the 3x3 kernel's mix
+    g_seed = 0x1234567u;
+    run<0, 0, 12, false>(512);
+    run<8, 2, 12, false>(512);
+    run<9, 2, 14, false>(512);
+    g_seed = 0;
     for (int grid = 512; grid >= 256; grid -= 256) {
         run<0, 0, 12, false>(grid);
         run<4, 0, 12, false>(grid);
