@@ -87,13 +87,13 @@ def make_desc(B, H, cin, cout, k, stride, residual, dev):
 def set_variant(v):
     for key in ("YOLO_AMD_CONV_NSTAGE", "YOLO_AMD_CONV_BK", "YOLO_AMD_CONV_TILE", "YOLO_AMD_CONV3",
                 "YOLO_AMD_CONV_AMUL", "YOLO_AMD_CONV_BN", "YOLO_AMD_CONV3_WAVES", "YOLO_AMD_CONV3_PRIO", "YOLO_AMD_CONV3_STG",
-                "YOLO_AMD_CONV_FP32EPI", "YOLO_AMD_CONV3_TC", "YOLO_AMD_CONV3_RING", "YOLO_AMD_CONV3_VAR", "YOLO_AMD_CONV3_FLAT", "YOLO_AMD_CONV3_SPLIT"):
+                "YOLO_AMD_CONV_FP32EPI", "YOLO_AMD_CONV_BN128_MIN", "YOLO_AMD_CONV3_TC", "YOLO_AMD_CONV3_RING", "YOLO_AMD_CONV3_VAR", "YOLO_AMD_CONV3_FLAT", "YOLO_AMD_CONV3_SPLIT"):
         os.environ.pop(key, None)
     for item in filter(None, v.split(",")):
         k, val = item.split("=")
         os.environ[{"ns": "YOLO_AMD_CONV_NSTAGE", "bk": "YOLO_AMD_CONV_BK",
                     "tile": "YOLO_AMD_CONV_TILE", "p3": "YOLO_AMD_CONV3",
-                    "am": "YOLO_AMD_CONV_AMUL", "bn": "YOLO_AMD_CONV_BN", "p3w": "YOLO_AMD_CONV3_WAVES", "prio": "YOLO_AMD_CONV3_PRIO", "stg": "YOLO_AMD_CONV3_STG", "f32": "YOLO_AMD_CONV_FP32EPI", "tc": "YOLO_AMD_CONV3_TC", "ring": "YOLO_AMD_CONV3_RING", "var": "YOLO_AMD_CONV3_VAR", "flat": "YOLO_AMD_CONV3_FLAT", "split": "YOLO_AMD_CONV3_SPLIT"}[k]] = val
+                    "am": "YOLO_AMD_CONV_AMUL", "bn": "YOLO_AMD_CONV_BN", "p3w": "YOLO_AMD_CONV3_WAVES", "prio": "YOLO_AMD_CONV3_PRIO", "stg": "YOLO_AMD_CONV3_STG", "f32": "YOLO_AMD_CONV_FP32EPI", "bn128min": "YOLO_AMD_CONV_BN128_MIN", "tc": "YOLO_AMD_CONV3_TC", "ring": "YOLO_AMD_CONV3_RING", "var": "YOLO_AMD_CONV3_VAR", "flat": "YOLO_AMD_CONV3_FLAT", "split": "YOLO_AMD_CONV3_SPLIT"}[k]] = val
 
 
 def apply_variant(v):
