@@ -476,7 +476,11 @@ def test_stem_in_one_launch_gives_the_separate_launches_bits(B, H, W):
     (2, 52, 52, 2, False, "igemm2"), (1, 37, 21, 2, False, "igemm2"), (3, 9, 16, 1, True, "igemm2"),
     (2, 104, 104, 2, False, "igemm2"), (1, 26, 26, 2, True, "igemm1"),
     (4, 104, 104, 1, True, "flat"), (8, 52, 52, 1, False, "flat"), (2, 152, 152, 1, True, "flat"),
-    (3, 104, 91, 1, True, "flat")])
+    (3, 104, 91, 1, True, "flat"),
+    # ragged shapes from a fixed seed: tiles that hang over the map on both sides, pixel counts that are not
+    # multiples of the 128-pixel tile, both strides, with and without a shortcut
+    *[(int(b), int(h), int(w), int(st), bool(rs), "igemm2") for b, h, w, st, rs in
+      np.random.RandomState(20260112).randint([1, 5, 5, 1, 0], [4, 70, 70, 3, 2], size=(10, 5))]])
 def test_a_1x1_layer_in_the_epilogue_of_the_3x3_layer_in_front_gives_the_two_launches_bits(B, H, W, stride, res, kind,
                                                                                            monkeypatch):
     """3x3 64 -> 128 (stride 2, or stride 1 with a shortcut) with fuse_next, then 1x1 128 -> 64
